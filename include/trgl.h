@@ -1,0 +1,185 @@
+/*
+ * trgl.h — C ABI of the MI355X tile rasterizer (drop-in for the reference's rasterize() hot path).
+ *
+ * The reference (AnnaUshnova/tinyrenderder) has no FFI: its hot path is the C++ source-level
+ * interface in our_gl.h.  Each entry point below names the reference interface it replaces
+ * (file:line under the reference tree).  Plain pointers and sizes only; no C++ / torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 (a TRGL_E_* code) on failure; the message is
+ *     available from trgl_last_error().  Nothing ever throws across this boundary.
+ *   - invalid triangles are silently dropped exactly as the reference does (our_gl.cpp:94-135);
+ *     that is not an error.
+ *   - one context per GPU, externally synchronised (the reference is single-threaded,
+ *     our_gl.cpp:12-22 keeps all state in unsynchronised globals).
+ *   - all arithmetic on the path is IEEE fp64 without contraction, in the reference's operation
+ *     order; framebuffer bytes and z-buffer bits are identical to the reference's.
+ */
+#ifndef TRGL_H
+#define TRGL_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRGL_VERSION 1
+#define TRGL_MAX_TEXTURES 16
+
+/* error codes */
+#define TRGL_OK            0
+#define TRGL_E_INVALID    -1   /* bad argument */
+#define TRGL_E_HIP        -2   /* HIP runtime error (message in trgl_last_error) */
+#define TRGL_E_NOMEM      -3
+#define TRGL_E_STATE      -4   /* call not valid in the current state */
+#define TRGL_E_UNSUPPORTED -5
+
+/* where the pointers handed to trgl_draw() live */
+#define TRGL_MEM_HOST   0      /* copied before trgl_draw returns */
+#define TRGL_MEM_DEVICE 1      /* HBM-resident; must stay valid until trgl_flush has completed */
+
+/*
+ * Shader kinds: the device-side restatements of IShader::fragment() bodies (our_gl.h:51).
+ * A C++ virtual cannot be called from a kernel, so a shader is a kind id + a POD uniform block +
+ * per-triangle varyings snapshotted at rasterize() call time.
+ *   FLAT    : one BGRA colour per triangle; fragment returns it unchanged.
+ *   GOURAUD : three per-vertex intensities (K=3 doubles per triangle) and one BGRA base colour per
+ *             triangle; fragment = base * (float)(i0*b0 + i1*b1 + i2*b2) with the semantics of
+ *             TGAColor::operator*(float) (tgaimage.h:55-62).
+ *   PHONG   : PhongShader::fragment (main.cpp:92-170), K=24 doubles per triangle.
+ *   EYE     : EyeShader::fragment   (main.cpp:220-261), K=24 doubles per triangle.
+ * Varyings layout for PHONG/EYE is the memory image of the shader's three member arrays
+ * (main.cpp:47-49,181-183): uv[3] (6 doubles), position_eye[3] (9), normal_eye[3] (9).
+ */
+#define TRGL_SHADER_FLAT    0
+#define TRGL_SHADER_GOURAUD 1
+#define TRGL_SHADER_PHONG   2
+#define TRGL_SHADER_EYE     3
+#define TRGL_NUM_SHADERS    4
+
+/* doubles of varyings per triangle for each kind */
+#define TRGL_VARY_FLAT    0
+#define TRGL_VARY_GOURAUD 3
+#define TRGL_VARY_PHONG   24
+#define TRGL_VARY_EYE     24
+
+/*
+ * Uniform block for PHONG / EYE (ignored by FLAT / GOURAUD; may be NULL for those).
+ * model_view is the value of the *global* ModelView when rasterize() was called: the reference
+ * reads the global inside fragment() (main.cpp:116), so a deferred renderer must snapshot it.
+ * Light directions are the shader members set by initLightDirections (main.cpp:55-69,187-197).
+ * tex_* are texture slots filled by trgl_upload_texture, or -1 for "material has no such map"
+ * (model.cpp:416-418,429-431,448-450 constants apply).
+ */
+typedef struct trgl_uniforms {
+    double  model_view[16];           /* row-major mat<4,4> (geometry.h:154-156) */
+    double  key_light_dir_eye[3];
+    double  fill_light_dir_eye[3];    /* PHONG only */
+    double  rim_light_dir_eye[3];
+    double  normal_map_strength;      /* PHONG only (main.cpp:51) */
+    int32_t tex_diffuse;
+    int32_t tex_normal;               /* PHONG only */
+    int32_t tex_specular;
+    int32_t reserved;
+} trgl_uniforms;
+
+/* The reference's diagnostic counters (our_gl.cpp:18-22), per context instead of process-global. */
+typedef struct trgl_stats {
+    uint64_t triangles_rasterized;    /* every rasterize() call, our_gl.cpp:90 */
+    uint64_t fragments_drawn;         /* every z-passing write, incl. later overwritten, :194 */
+    int32_t  min_x, min_y, max_x, max_y;   /* union of clamped triangle bboxes, :138-141 */
+    double   min_z, max_z;            /* range of written z, :197-198 */
+} trgl_stats;
+
+/* phases timed with HIP events on the context's stream when profiling is on */
+#define TRGL_PHASE_SETUP   0   /* per-triangle setup + tile-overlap count */
+#define TRGL_PHASE_BIN     1   /* scan + pair expansion + stable tile sort */
+#define TRGL_PHASE_RASTER  2   /* tile raster (coverage, z-test, fragment) + tile flush */
+#define TRGL_PHASE_TOTAL   3   /* first kernel to last kernel of a flush */
+#define TRGL_NUM_PHASES    4
+
+typedef struct trgl_ctx trgl_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+
+/* Replaces: TGAImage framebuffer(W,H,bpp) (tgaimage.cpp:8-17) + init_zbuffer(W,H)
+ * (our_gl.cpp:72-74) + init_viewport(0,0,W,H) (our_gl.cpp:59-69).  bpp is 1, 3 or 4
+ * (TGAImage::Format, tgaimage.h:69).  The framebuffer starts cleared to TGAColor() = (0,0,0,255)
+ * (tgaimage.h:33), the z-buffer to +inf, the stats to their initial values (our_gl.cpp:18-22). */
+int trgl_create(int device, int width, int height, int bpp, trgl_ctx** out);
+int trgl_destroy(trgl_ctx* ctx);
+const char* trgl_last_error(const trgl_ctx* ctx /* may be NULL: creation errors */);
+
+/* ---- pipeline state ------------------------------------------------------------------------ */
+
+/* Replaces: the global `Viewport` (our_gl.cpp:14); m is the row-major 4x4. */
+int trgl_set_viewport(trgl_ctx* ctx, const double m[16]);
+/* Replaces: init_viewport(x,y,w,h) (our_gl.cpp:59-69). */
+int trgl_init_viewport(trgl_ctx* ctx, int x, int y, int w, int h);
+/* Replaces: TGAImage(w,h,bpp,clear) fill (tgaimage.cpp:8-17) and init_zbuffer (our_gl.cpp:72-74).
+ * clear_bgra NULL = TGAColor(); z_clear is normally +infinity. */
+int trgl_clear(trgl_ctx* ctx, const uint8_t clear_bgra[4], double z_clear);
+/* Replaces: TGAImage textures held by Model::materials[0] (model.h:34-44); row-major, `bpp`
+ * bytes per texel in B,G,R[,A] order, row 0 first, exactly TGAImage::buffer() (tgaimage.h:93). */
+int trgl_upload_texture(trgl_ctx* ctx, int slot, const uint8_t* texels, int w, int h, int bpp);
+
+/* Multi-GPU: restrict this context to framebuffer rows [y0,y1) (a horizontal strip).  Triangles
+ * are still all counted/bboxed (setup is replicated), pixels outside the strip are not touched. */
+int trgl_set_strip(trgl_ctx* ctx, int y0, int y1);
+
+/* ---- submission ---------------------------------------------------------------------------- */
+
+/* Replaces: n consecutive calls of rasterize(clip, shader, framebuffer) (our_gl.h:58,
+ * our_gl.cpp:89-201) with the same shader object.
+ *   clip     : n x 12 doubles, the `Triangle` = vec<4>[3] memory image (our_gl.h:55)
+ *   varyings : n x K doubles (K by kind, above) or NULL when K = 0
+ *   colors   : n x uint32 (b | g<<8 | r<<16 | a<<24) for FLAT/GOURAUD, else NULL
+ * Triangles are drawn in array order after everything submitted earlier (submission order is
+ * observable: z ties keep the earlier triangle, our_gl.cpp:165). */
+int trgl_draw(trgl_ctx* ctx, int shader_kind, const trgl_uniforms* uniforms,
+              const double* clip, const double* varyings, const uint32_t* colors,
+              uint64_t n, int mem_kind);
+
+/* Execute everything submitted so far (asynchronously on the context's stream). */
+int trgl_flush(trgl_ctx* ctx);
+/* Wait for the context's stream. */
+int trgl_sync(trgl_ctx* ctx);
+
+/* ---- results ------------------------------------------------------------------------------- */
+
+/* Replaces: TGAImage::buffer() / get() (tgaimage.h:93, tgaimage.cpp:24-30): W*H*bpp bytes,
+ * index (x + y*W)*bpp, B,G,R[,A].  Implies flush + sync. */
+int trgl_read_framebuffer(trgl_ctx* ctx, uint8_t* dst);
+int trgl_write_framebuffer(trgl_ctx* ctx, const uint8_t* src);
+/* Replaces: direct access to the global std::vector<double> zbuffer (our_gl.h:20;
+ * main.cpp:700,730,751,759): W*H doubles, index x + y*W. */
+int trgl_read_zbuffer(trgl_ctx* ctx, double* dst);
+int trgl_write_zbuffer(trgl_ctx* ctx, const double* src);
+/* Replaces: print_render_stats() (our_gl.cpp:204-210), as a struct. Implies flush + sync. */
+int trgl_get_stats(trgl_ctx* ctx, trgl_stats* out);
+int trgl_reset_stats(trgl_ctx* ctx);
+/* Formats exactly the line print_render_stats() writes to stderr (our_gl.cpp:205-209). */
+int trgl_format_stats(const trgl_stats* s, char* buf, size_t buflen);
+
+/* Device-resident results, for collectives (RCCL all-gather of strips) and on-device consumers.
+ * Valid until trgl_destroy. Rows outside the context's strip hold stale/cleared data. */
+void* trgl_framebuffer_device_ptr(trgl_ctx* ctx);
+void* trgl_zbuffer_device_ptr(trgl_ctx* ctx);
+/* The hipStream_t all work of this context is enqueued on. */
+void* trgl_stream(trgl_ctx* ctx);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+
+int trgl_set_profiling(trgl_ctx* ctx, int on);
+/* Cumulative milliseconds per phase since the last reset and the number of flushes measured. */
+int trgl_get_phase_ms(trgl_ctx* ctx, double ms[TRGL_NUM_PHASES], uint64_t* flushes);
+int trgl_reset_phase_ms(trgl_ctx* ctx);
+/* Implementation traffic counters of the last flush: tri-tile pairs produced by binning. */
+int trgl_get_last_flush_info(trgl_ctx* ctx, uint64_t* triangles, uint64_t* pairs, uint64_t* tiles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRGL_H */

@@ -1,0 +1,204 @@
+"""ctypes binding of the CPU oracle (oracle/libtrgl_oracle.so) — TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Also holds the writer/runner for oracle/_ref/ref_harness (the reference's own rasterize() compiled
+in place from /root/reference; exists only in the build container).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtrgl_oracle.so")
+REF_HARNESS = os.path.join(HERE, "_ref", "ref_harness")
+
+MAX_TEXTURES = 16
+FLAT, GOURAUD, PHONG, EYE = 0, 1, 2, 3
+VARY = {FLAT: 0, GOURAUD: 3, PHONG: 24, EYE: 24}
+
+
+class Uniforms(C.Structure):
+    _fields_ = [("model_view", C.c_double * 16), ("key_light_dir_eye", C.c_double * 3),
+                ("fill_light_dir_eye", C.c_double * 3), ("rim_light_dir_eye", C.c_double * 3),
+                ("normal_map_strength", C.c_double), ("tex_diffuse", C.c_int32), ("tex_normal", C.c_int32),
+                ("tex_specular", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("triangles_rasterized", C.c_uint64), ("fragments_drawn", C.c_uint64),
+                ("min_x", C.c_int32), ("min_y", C.c_int32), ("max_x", C.c_int32), ("max_y", C.c_int32),
+                ("min_z", C.c_double), ("max_z", C.c_double)]
+
+    def astuple(self):
+        return (self.triangles_rasterized, self.fragments_drawn, self.min_x, self.min_y, self.max_x, self.max_y,
+                self.min_z, self.max_z)
+
+
+class Texture(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("w", C.c_int), ("h", C.c_int), ("bpp", C.c_int)]
+
+
+class Target(C.Structure):
+    _fields_ = [("fb", C.c_void_p), ("zbuf", C.c_void_p), ("w", C.c_int), ("h", C.c_int), ("bpp", C.c_int),
+                ("clip_y0", C.c_int), ("clip_y1", C.c_int), ("viewport", C.c_double * 16), ("stats", Stats)]
+
+
+def make_uniforms(model_view=None, key=(0, 0, 1), fill=(0, 0, 1), rim=(0, 0, 1), normal_map_strength=1.0,
+                  tex_diffuse=-1, tex_normal=-1, tex_specular=-1) -> Uniforms:
+    u = Uniforms()
+    mv = np.eye(4) if model_view is None else np.asarray(model_view, np.float64)
+    u.model_view[:] = mv.reshape(16).tolist()
+    u.key_light_dir_eye[:] = list(map(float, key))
+    u.fill_light_dir_eye[:] = list(map(float, fill))
+    u.rim_light_dir_eye[:] = list(map(float, rim))
+    u.normal_map_strength = float(normal_map_strength)
+    u.tex_diffuse, u.tex_normal, u.tex_specular, u.reserved = tex_diffuse, tex_normal, tex_specular, 0
+    return u
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} missing: run `make -C oracle` (or __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        L.orc_init_viewport.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_stats_init.argtypes = [C.POINTER(Stats)]
+        L.orc_clear.argtypes = [C.POINTER(Target), C.c_void_p, C.c_double]
+        L.orc_rasterize.argtypes = [C.POINTER(Target), C.c_int, C.POINTER(Uniforms), C.POINTER(Texture),
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.orc_fragment.argtypes = [C.c_int, C.POINTER(Uniforms), C.POINTER(Texture), C.c_void_p, C.c_uint32,
+                                   C.POINTER(C.c_double), C.POINTER(C.c_uint8)]
+        L.orc_fragment.restype = C.c_int
+        L.orc_normalized3.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_mat4_mul_dir.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_interp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class Oracle:
+    """A framebuffer + z-buffer + stats driven through the CPU restatement."""
+
+    def __init__(self, width, height, bpp=3, viewport=None, clear_bgra=None, z_clear=np.inf, strip=None):
+        self.L = lib()
+        self.w, self.h, self.bpp = width, height, bpp
+        self.fb = np.zeros((height, width, bpp), np.uint8)
+        self.z = np.empty((height, width), np.float64)
+        self.t = Target()
+        self.t.fb, self.t.zbuf = self.fb.ctypes.data, self.z.ctypes.data
+        self.t.w, self.t.h, self.t.bpp = width, height, bpp
+        self.t.clip_y0, self.t.clip_y1 = (0, height) if strip is None else strip
+        vp = np.asarray(viewport, np.float64).reshape(16) if viewport is not None else None
+        if vp is None:
+            self.L.orc_init_viewport(self.t.viewport, 0, 0, width, height)
+        else:
+            self.t.viewport[:] = vp.tolist()
+        self.L.orc_stats_init(C.byref(self.t.stats))
+        self.textures = (Texture * MAX_TEXTURES)()
+        self._tex_keep = {}
+        cb = None if clear_bgra is None else np.asarray(clear_bgra, np.uint8)
+        self.L.orc_clear(C.byref(self.t), None if cb is None else cb.ctypes.data, float(z_clear))
+
+    def upload_texture(self, slot, texels):
+        t = np.ascontiguousarray(texels, np.uint8)
+        if t.ndim == 2:
+            t = t[..., None]
+        self._tex_keep[slot] = t
+        self.textures[slot] = Texture(t.ctypes.data, t.shape[1], t.shape[0], t.shape[2])
+
+    def draw(self, kind, clip, varyings=None, colors=None, uniforms=None):
+        clip = np.ascontiguousarray(clip, np.float64)
+        n = clip.shape[0]
+        K = VARY[kind]
+        v = None if K == 0 else np.ascontiguousarray(varyings, np.float64)
+        if v is not None:
+            assert v.shape == (n, K), v.shape
+        c = None if colors is None else np.ascontiguousarray(colors, np.uint32)
+        u = uniforms if uniforms is not None else make_uniforms()
+        self.L.orc_rasterize(C.byref(self.t), kind, C.byref(u), self.textures, clip.ctypes.data,
+                             None if v is None else v.ctypes.data, None if c is None else c.ctypes.data, n)
+
+    @property
+    def stats(self):
+        return self.t.stats.astuple()
+
+
+# ---------------------------------------------------------------------------------------------
+# reference harness (build container only)
+# ---------------------------------------------------------------------------------------------
+def ref_available() -> bool:
+    return os.path.exists(REF_HARNESS)
+
+
+def _pad8(b: bytes) -> bytes:
+    return b + b"\0" * ((8 - len(b) % 8) % 8)
+
+
+def write_scene(path, width, height, bpp, viewport, draws, textures=None, clear_bgra=(0, 0, 0, 255), z_clear=np.inf):
+    """draws: list of (kind, Uniforms|None, clip, varyings|None, colors|None); textures: {slot: array}."""
+    textures = textures or {}
+    with open(path, "wb") as f:
+        f.write(b"TRGSCN01")
+        f.write(struct.pack("<6i", width, height, bpp, len(draws), len(textures), 0))
+        f.write(np.asarray(viewport, np.float64).reshape(16).tobytes())
+        f.write(bytes(bytearray(clear_bgra)) + b"\0\0\0\0")
+        f.write(struct.pack("<d", float(z_clear)))
+        for slot, t in textures.items():
+            t = np.ascontiguousarray(t, np.uint8)
+            if t.ndim == 2:
+                t = t[..., None]
+            f.write(struct.pack("<4i", slot, t.shape[1], t.shape[0], t.shape[2]))
+            f.write(_pad8(t.tobytes()))
+        for kind, u, clip, vary, colors in draws:
+            clip = np.ascontiguousarray(clip, np.float64)
+            n = clip.shape[0]
+            f.write(struct.pack("<iiQ", kind, 0, n))
+            f.write(bytes(u if u is not None else make_uniforms()))
+            f.write(clip.tobytes())
+            if VARY[kind]:
+                f.write(np.ascontiguousarray(vary, np.float64).tobytes())
+            cols = np.ascontiguousarray(colors, np.uint32) if colors is not None else np.full(n, 0xFFFFFFFF, np.uint32)
+            f.write(_pad8(cols.tobytes()))
+
+
+def parse_stats_line(line: str):
+    """'DEBUG: triangles=N fragments_drawn=M bbox=[a,b] - [c,d] z-range=[lo,hi]' (our_gl.cpp:205-209)."""
+    import re
+    m = re.search(r"triangles=(\d+) fragments_drawn=(\d+) bbox=\[(-?\d+),(-?\d+)\] - \[(-?\d+),(-?\d+)\] z-range=\[([^,]+),([^\]]+)\]", line)
+    tri, frag, x0, y0, x1, y1 = (int(m.group(i)) for i in range(1, 7))
+    return tri, frag, x0, y0, x1, y1, m.group(7), m.group(8)
+
+
+def run_reference(width, height, bpp, viewport, draws, textures=None, clear_bgra=(0, 0, 0, 255), z_clear=np.inf):
+    """Render with the reference's own rasterize(); returns (fb[h,w,bpp] u8, z[h,w] f64, stats line)."""
+    with tempfile.TemporaryDirectory() as d:
+        sp, op = os.path.join(d, "scene.bin"), os.path.join(d, "out.bin")
+        write_scene(sp, width, height, bpp, viewport, draws, textures, clear_bgra, z_clear)
+        subprocess.run([REF_HARNESS, "scene", sp, op], check=True)
+        raw = open(op, "rb").read()
+    nfb = width * height * bpp
+    fb = np.frombuffer(raw, np.uint8, nfb).reshape(height, width, bpp).copy()
+    off = (nfb + 7) & ~7
+    z = np.frombuffer(raw, np.float64, width * height, off).reshape(height, width).copy()
+    off += width * height * 8
+    (ln,) = struct.unpack_from("<i", raw, off)
+    line = raw[off + 4: off + 4 + ln].decode()
+    return fb, z, line.strip()
+
+
+def format_stats_line(stats_tuple) -> str:
+    """The print_render_stats() line (our_gl.cpp:205-209) for an oracle/GPU stats tuple."""
+    tri, frag, x0, y0, x1, y1, zlo, zhi = stats_tuple
+    lo = f"{zlo:.6f}" if np.isfinite(zlo) else "inf"
+    hi = f"{zhi:.6f}" if np.isfinite(zhi) else "-inf"
+    return f"DEBUG: triangles={tri} fragments_drawn={frag} bbox=[{x0},{y0}] - [{x1},{y1}] z-range=[{lo},{hi}]"

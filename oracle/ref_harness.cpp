@@ -1,0 +1,184 @@
+// ref_harness.cpp — TEST INFRASTRUCTURE, NOT PRODUCT.
+//
+// Drives the reference's own rasterize() (compiled, unmodified, from /root/reference/our_gl.cpp +
+// tgaimage.cpp where they lie — see oracle/Makefile; nothing of the reference is copied here) over
+// scene files written by tests/refharness.py, and dumps framebuffer, z-buffer and the
+// print_render_stats() line.  Used only in the build container to (1) validate the C restatement
+// oracle/trgl_oracle.c bit-for-bit and (2) generate the golden fixtures under tests/golden/.
+//
+// One process per scene: the reference's diagnostic counters are file-static and never reset
+// (our_gl.cpp:18-22).
+//
+// Shaders here are IShader subclasses (our_gl.h:36-52):
+//   FLAT / GOURAUD are defined on the reference's own TGAColor (tgaimage.h:29-63);
+//   PHONG / EYE call the C restatement's fragment (orc_fragment): main.cpp cannot be compiled here
+//   (model.h includes Assimp), so those bodies are NOT pinned by this harness — what it pins for
+//   them is everything around the up-call: the perspective-correct bary handed to fragment(), the
+//   z-test order and TGAImage::set of the returned colour.
+// Mode "vecops" evaluates geometry.h / tgaimage.h value ops on given inputs so the restatement's
+// helpers can be compared with the real ones.
+
+#include "our_gl.h"          // from -I/root/reference
+#include "trgl_oracle.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <vector>
+
+namespace {
+
+struct Reader {
+    std::vector<unsigned char> buf; size_t pos = 0;
+    bool load(const char* path) {
+        std::ifstream in(path, std::ios::binary);
+        if (!in) return false;
+        buf.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
+        return true;
+    }
+    template <class T> T get() { T v; std::memcpy(&v, &buf[pos], sizeof(T)); pos += sizeof(T); return v; }
+    const unsigned char* take(size_t n) { const unsigned char* p = &buf[pos]; pos += n; return p; }
+    void align8() { pos = (pos + 7) & ~size_t(7); }
+};
+
+TGAColor color_from_packed(uint32_t v) {
+    return TGAColor((uint8_t)((v >> 16) & 0xff), (uint8_t)((v >> 8) & 0xff), (uint8_t)(v & 0xff), (uint8_t)((v >> 24) & 0xff));
+}
+
+struct FlatShader : IShader {
+    TGAColor color;
+    std::pair<bool, TGAColor> fragment(const vec3) const override { return { false, color }; }
+};
+
+struct GouraudShader : IShader {
+    double intensity[3]; TGAColor base;
+    std::pair<bool, TGAColor> fragment(const vec3 bar) const override {
+        double i = intensity[0] * bar[0] + intensity[1] * bar[1] + intensity[2] * bar[2];
+        return { false, base * (float)i };      // TGAColor::operator*(float), tgaimage.h:55-62
+    }
+};
+
+struct RestatedFragShader : IShader {
+    int kind; const trgl_uniforms* u; const orc_texture* tex; const double* vary;
+    std::pair<bool, TGAColor> fragment(const vec3 bar) const override {
+        double b[3] = { bar[0], bar[1], bar[2] };
+        uint8_t bgra[4];
+        int bytespp = orc_fragment(kind, u, tex, vary, 0, b, bgra);
+        TGAColor c(bgra, (uint8_t)4);
+        c.bytespp = (uint8_t)bytespp;
+        return { false, c };
+    }
+};
+
+int run_scene(const char* in_path, const char* out_path) {
+    Reader r;
+    if (!r.load(in_path)) { std::fprintf(stderr, "cannot read %s\n", in_path); return 2; }
+    if (std::memcmp(r.take(8), "TRGSCN01", 8) != 0) { std::fprintf(stderr, "bad magic\n"); return 2; }
+    int W = r.get<int32_t>(), H = r.get<int32_t>(), bpp = r.get<int32_t>();
+    int ndraws = r.get<int32_t>(), ntex = r.get<int32_t>(); r.get<int32_t>();
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Viewport[i][j] = r.get<double>();
+    uint8_t clear[4]; std::memcpy(clear, r.take(4), 4); r.take(4);
+    double zclear = r.get<double>();
+
+    std::vector<orc_texture> tex(TRGL_MAX_TEXTURES, orc_texture{ nullptr, 0, 0, 0 });
+    for (int t = 0; t < ntex; ++t) {
+        int slot = r.get<int32_t>(), w = r.get<int32_t>(), h = r.get<int32_t>(), tb = r.get<int32_t>();
+        tex[slot] = orc_texture{ r.take((size_t)w * h * tb), w, h, tb };
+        r.align8();
+    }
+
+    TGAColor clear_color(clear, (uint8_t)4);
+    TGAImage framebuffer(W, H, bpp, clear_color);
+    init_zbuffer(W, H);
+    if (!(zclear == std::numeric_limits<double>::infinity()))
+        for (auto& z : zbuffer) z = zclear;
+
+    for (int d = 0; d < ndraws; ++d) {
+        int kind = r.get<int32_t>(); r.get<int32_t>();
+        uint64_t n = r.get<uint64_t>();
+        trgl_uniforms u; std::memcpy(&u, r.take(sizeof(u)), sizeof(u));
+        const double* clip = (const double*)r.take(n * 12 * sizeof(double));
+        int K = kind == TRGL_SHADER_GOURAUD ? TRGL_VARY_GOURAUD : (kind == TRGL_SHADER_PHONG || kind == TRGL_SHADER_EYE) ? 24 : 0;
+        const double* vary = (const double*)r.take(n * K * sizeof(double));
+        const uint32_t* colors = (const uint32_t*)r.take(n * sizeof(uint32_t));
+        r.align8();
+
+        FlatShader flat; GouraudShader gour; RestatedFragShader rest;
+        rest.kind = kind; rest.u = &u; rest.tex = tex.data();
+        for (uint64_t i = 0; i < n; ++i) {
+            vec4 tri[3];
+            for (int v = 0; v < 3; ++v) for (int c = 0; c < 4; ++c) tri[v][c] = clip[i * 12 + v * 4 + c];
+            if (kind == TRGL_SHADER_FLAT) {
+                flat.color = color_from_packed(colors[i]);
+                rasterize(tri, flat, framebuffer);
+            } else if (kind == TRGL_SHADER_GOURAUD) {
+                for (int v = 0; v < 3; ++v) gour.intensity[v] = vary[i * 3 + v];
+                gour.base = color_from_packed(colors[i]);
+                rasterize(tri, gour, framebuffer);
+            } else {
+                rest.vary = vary + i * 24;
+                rasterize(tri, rest, framebuffer);
+            }
+        }
+    }
+
+    std::ostringstream captured;
+    std::streambuf* old = std::cerr.rdbuf(captured.rdbuf());
+    print_render_stats();                                   // our_gl.cpp:204-210
+    std::cerr.rdbuf(old);
+    std::string line = captured.str();
+
+    std::ofstream out(out_path, std::ios::binary);
+    size_t fb_bytes = (size_t)W * H * bpp;
+    out.write((const char*)framebuffer.buffer(), fb_bytes);
+    static const char pad[8] = { 0 };
+    out.write(pad, (8 - fb_bytes % 8) % 8);
+    out.write((const char*)zbuffer.data(), zbuffer.size() * sizeof(double));
+    int32_t len = (int32_t)line.size();
+    out.write((const char*)&len, 4);
+    out.write(line.data(), len);
+    return out ? 0 : 3;
+}
+
+// vecops: input = int32 count, then per item 3+3+16+9+3+1 doubles (v, n, M, v0v1v2, b, intensity) and
+// uint32 colour; output per item: normalized(v)[3], (M*vec4(n,0)).xyz[3], v0*b0+v1*b1+v2*b2 [3],
+// then 4 bytes (colour * (float)intensity).
+int run_vecops(const char* in_path, const char* out_path) {
+    Reader r;
+    if (!r.load(in_path)) return 2;
+    int count = r.get<int32_t>(); r.get<int32_t>();
+    std::ofstream out(out_path, std::ios::binary);
+    for (int i = 0; i < count; ++i) {
+        vec3 v, n, v0, v1, v2, b; mat<4, 4> M;
+        for (int k = 0; k < 3; ++k) v[k] = r.get<double>();
+        for (int k = 0; k < 3; ++k) n[k] = r.get<double>();
+        for (int a = 0; a < 4; ++a) for (int c = 0; c < 4; ++c) M[a][c] = r.get<double>();
+        for (int k = 0; k < 3; ++k) v0[k] = r.get<double>();
+        for (int k = 0; k < 3; ++k) v1[k] = r.get<double>();
+        for (int k = 0; k < 3; ++k) v2[k] = r.get<double>();
+        for (int k = 0; k < 3; ++k) b[k] = r.get<double>();
+        double inten = r.get<double>();
+        uint32_t packed = r.get<uint32_t>(); r.get<uint32_t>();
+        vec3 nv = normalized(v);
+        vec3 md = (M * make_vec4(n[0], n[1], n[2], 0.0)).xyz();
+        vec3 ip = v0 * b[0] + v1 * b[1] + v2 * b[2];
+        TGAColor sc = color_from_packed(packed) * (float)inten;
+        double o[9] = { nv[0], nv[1], nv[2], md[0], md[1], md[2], ip[0], ip[1], ip[2] };
+        out.write((const char*)o, sizeof(o));
+        out.write((const char*)sc.bgra, 4);
+        static const char pad[4] = { 0 };
+        out.write(pad, 4);
+    }
+    return out ? 0 : 3;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc == 4 && std::strcmp(argv[1], "scene") == 0) return run_scene(argv[2], argv[3]);
+    if (argc == 4 && std::strcmp(argv[1], "vecops") == 0) return run_vecops(argv[2], argv[3]);
+    std::fprintf(stderr, "usage: ref_harness scene|vecops <in> <out>\n");
+    return 1;
+}

@@ -1,0 +1,68 @@
+/*
+ * trgl_oracle.h — TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * CPU restatement (plain C, fp64, no contraction) of the reference's rasterize() hot path:
+ * /root/reference/our_gl.cpp:59-74,77-86,89-201 plus the fragment bodies main.cpp:92-170,220-261
+ * and the samplers model.cpp:415-459.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this; the product library never does.
+ *
+ * Pinning: rasterize()/barycentric()/TGAImage::set/TGAColor::operator* are pinned bit-for-bit
+ * against the reference itself compiled from /root/reference (oracle/_ref, see oracle/Makefile
+ * and tests/golden/).  The PHONG / EYE fragment bodies live in main.cpp, which cannot be compiled
+ * here (model.h needs Assimp, absent): they are restated from the text and checked against the
+ * same restatement run through the reference's own rasterize()+geometry.h — "parity unpinned"
+ * against a compiled main.cpp.
+ */
+#ifndef TRGL_ORACLE_H
+#define TRGL_ORACLE_H
+
+#include <stdint.h>
+#include "../include/trgl.h"   /* POD structs shared with the C ABI: trgl_uniforms, trgl_stats */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_texture {
+    const uint8_t* data;   /* NULL = material has no such map */
+    int w, h, bpp;
+} orc_texture;
+
+typedef struct orc_target {
+    uint8_t* fb;           /* w*h*bpp bytes, TGAImage layout (tgaimage.cpp:32-39) */
+    double*  zbuf;         /* w*h doubles (our_gl.cpp:72-74) */
+    int      w, h, bpp;
+    int      clip_y0, clip_y1;   /* rows rasterized: [clip_y0, clip_y1); whole image = [0,h) */
+    double   viewport[16]; /* row-major mat<4,4> (our_gl.cpp:14) */
+    trgl_stats stats;      /* our_gl.cpp:18-22 */
+} orc_target;
+
+/* our_gl.cpp:59-69 */
+void orc_init_viewport(double vp[16], int x, int y, int w, int h);
+/* our_gl.cpp:18-22 initial values */
+void orc_stats_init(trgl_stats* s);
+/* tgaimage.cpp:8-17 + our_gl.cpp:72-74 */
+void orc_clear(orc_target* t, const uint8_t clear_bgra[4], double z_clear);
+
+/* n calls of rasterize() (our_gl.cpp:89-201) in array order. */
+void orc_rasterize(orc_target* t, int shader_kind, const trgl_uniforms* u,
+                   const orc_texture* textures /* [TRGL_MAX_TEXTURES] or NULL */,
+                   const double* clip, const double* varyings, const uint32_t* colors, uint64_t n);
+
+/* One IShader::fragment() call (our_gl.cpp:187) of the given kind: bary is the perspective-correct
+ * barycentric vector the rasterizer passes.  Returns bytespp of the colour (tgaimage.h:31). */
+int orc_fragment(int shader_kind, const trgl_uniforms* u, const orc_texture* textures,
+                 const double* varyings, uint32_t packed_color, const double bary[3], uint8_t out_bgra[4]);
+
+/* value-math helpers exposed so tests can pin them against the reference's geometry.h */
+void orc_normalized3(const double v[3], double out[3]);                       /* geometry.h:136-140 */
+void orc_mat4_mul_dir(const double m[16], const double n[3], double out[3]);  /* geometry.h:186-192, w=0 */
+void orc_interp(const double* v0, const double* v1, const double* v2, const double b[3], int n, double* out);
+
+/* FNV-1a 64 over raw bytes (used for fixtures) */
+uint64_t orc_fnv1a64(const void* p, uint64_t nbytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
