@@ -1,0 +1,171 @@
+"""Named parity scenes shared by the golden-fixture generator, the oracle tests and the GPU tests.
+
+Each builder returns a dict: width, height, bpp, viewport (4x4), draws = [(kind, uniforms|None, clip,
+varyings|None, colors|None)], textures = {slot: array}, clear (4 bytes), zclear.
+Inputs come from tinyrenderder_amd.scenes (bit-reproducible everywhere).
+"""
+import numpy as np
+
+from tinyrenderder_amd import scenes
+from tinyrenderder_amd.api import FLAT, GOURAUD, PHONG, EYE, make_uniforms
+
+DEFAULT_CLEAR = (0, 0, 0, 255)
+
+
+def _case(w, h, draws, bpp=3, viewport=None, textures=None, clear=DEFAULT_CLEAR, zclear=np.inf):
+    return dict(width=w, height=h, bpp=bpp, viewport=scenes.init_viewport(0, 0, w, h) if viewport is None else viewport,
+                draws=draws, textures=textures or {}, clear=tuple(clear), zclear=zclear)
+
+
+def flat_small_64():
+    clip, col = scenes.random_triangles(300, 64, 64, seed=11, rmin=2, rmax=32)
+    return _case(64, 64, [(FLAT, None, clip, None, col)])
+
+
+def flat_800():          # BASELINE config 0 shape: 800x800, flat, CPU-runnable
+    clip, col = scenes.random_triangles(100_000, 800, 800, seed=12, rmin=1, rmax=16)
+    return _case(800, 800, [(FLAT, None, clip, None, col)])
+
+
+def flat_persp_512():
+    clip, col = scenes.random_triangles(20_000, 512, 512, seed=13, rmin=2, rmax=64, perspective_w=True)
+    return _case(512, 512, [(FLAT, None, clip, None, col)])
+
+
+def flat_big_tris_512():
+    clip, col = scenes.random_triangles(400, 512, 512, seed=14, rmin=64, rmax=512)
+    return _case(512, 512, [(FLAT, None, clip, None, col)])
+
+
+def edge_256():
+    clip, col = scenes.edge_case_triangles(256, 256)
+    return _case(256, 256, [(FLAT, None, clip, None, col)])
+
+
+def grid_256():
+    clip, col = scenes.shared_edge_grid(8, 8, 256, 256)
+    return _case(256, 256, [(FLAT, None, clip, None, col)])
+
+
+def grid_fine_128():
+    clip, col = scenes.shared_edge_grid(32, 32, 128, 128, z_slope=0.0)   # all z equal: every shared pixel is a tie
+    return _case(128, 128, [(FLAT, None, clip, None, col)])
+
+
+def gouraud_256_rgba():
+    clip, col = scenes.random_triangles(5000, 256, 256, seed=15, rmin=2, rmax=64, perspective_w=True)
+    inten = scenes.SplitMix64(5).uniform(5000 * 3, -0.2, 1.3).reshape(5000, 3)
+    return _case(256, 256, [(GOURAUD, None, clip, inten, col)], bpp=4)
+
+
+def _head(level, w, h, tex):
+    hd = scenes.head_standin(level, w, h)
+    d, n, s = scenes.procedural_textures(tex)
+    return hd, {0: d, 1: n, 2: s}
+
+
+def phong_512():
+    hd, tx = _head(4, 512, 512, 256)
+    u = make_uniforms(hd["model_view"], hd["key"], hd["fill"], hd["rim"], 1.0, 0, 1, 2)
+    return _case(512, 512, [(PHONG, u, hd["clip"], hd["varyings"], None)], textures=tx)
+
+
+def phong_nomaps_256():
+    hd, _ = _head(3, 256, 256, 64)
+    u = make_uniforms(hd["model_view"], hd["key"], hd["fill"], hd["rim"], 0.5, -1, -1, -1)
+    return _case(256, 256, [(PHONG, u, hd["clip"], hd["varyings"], None)])
+
+
+def eye_256():
+    hd, tx = _head(3, 256, 256, 128)
+    u = make_uniforms(hd["model_view"], hd["key"], hd["fill"], hd["rim"], 1.0, 0, -1, 2)
+    return _case(256, 256, [(EYE, u, hd["clip"], hd["varyings"], None)], textures=tx)
+
+
+def multi_draw_320x200():
+    """main.cpp's frame shape: background PHONG (strength 0.5), PHONG head, EYE on top, flat overlay."""
+    w, h = 320, 200
+    hd, tx = _head(3, w, h, 128)
+    big = scenes.head_standin(2, w, h, seed=99, distance=1.6)
+    u_bg = make_uniforms(big["model_view"], big["key"], big["fill"], big["rim"], 0.5, 0, 1, -1)
+    u_hd = make_uniforms(hd["model_view"], hd["key"], hd["fill"], hd["rim"], 1.0, 0, 1, 2)
+    u_ey = make_uniforms(hd["model_view"], hd["key"], hd["fill"], hd["rim"], 1.0, 0, -1, -1)
+    small = scenes.head_standin(2, w, h, seed=5, distance=4.0)
+    fclip, fcol = scenes.random_triangles(500, w, h, seed=17, rmin=2, rmax=24)
+    return _case(w, h, [(PHONG, u_bg, big["clip"], big["varyings"], None),
+                        (PHONG, u_hd, hd["clip"], hd["varyings"], None),
+                        (EYE, u_ey, small["clip"], small["varyings"], None),
+                        (FLAT, None, fclip, None, fcol)], textures=tx, clear=(30, 20, 10, 255))
+
+
+def odd_dims_101x67():
+    clip, col = scenes.random_triangles(2000, 101, 67, seed=18, rmin=1, rmax=24)
+    return _case(101, 67, [(FLAT, None, clip, None, col)])
+
+
+def gray_bpp1_96x64():
+    clip, col = scenes.random_triangles(1500, 96, 64, seed=19, rmin=1, rmax=24)
+    return _case(96, 64, [(FLAT, None, clip, None, col)], bpp=1)
+
+
+def viewport_offset_256x160():
+    clip, col = scenes.random_triangles(3000, 200, 120, seed=20, rmin=1, rmax=32)
+    return _case(256, 160, [(FLAT, None, clip, None, col)], viewport=scenes.init_viewport(16, 8, 200, 120))
+
+
+def zclear_finite_128():
+    clip, col = scenes.random_triangles(3000, 128, 128, seed=21, rmin=2, rmax=32)
+    return _case(128, 128, [(FLAT, None, clip, None, col)], bpp=4, clear=(7, 8, 9, 10), zclear=0.25)
+
+
+def empty_scene_64():
+    return _case(64, 64, [])
+
+
+CASES = {f.__name__: f for f in (
+    flat_small_64, flat_800, flat_persp_512, flat_big_tris_512, edge_256, grid_256, grid_fine_128, gouraud_256_rgba,
+    phong_512, phong_nomaps_256, eye_256, multi_draw_320x200, odd_dims_101x67, gray_bpp1_96x64,
+    viewport_offset_256x160, zclear_finite_128, empty_scene_64)}
+
+# cases whose full buffers are stored in tests/golden/ (small enough to commit)
+FULL_BUFFER_CASES = ("flat_small_64", "odd_dims_101x67", "gray_bpp1_96x64")
+
+
+def run_oracle(case, strip=None):
+    """Render a case with the CPU oracle; returns (fb, z, stats tuple)."""
+    from oracle import orc
+    o = orc.Oracle(case["width"], case["height"], case["bpp"], viewport=case["viewport"], clear_bgra=case["clear"],
+                   z_clear=case["zclear"], strip=strip)
+    for slot, t in case["textures"].items():
+        o.upload_texture(slot, t)
+    for kind, u, clip, vary, col in case["draws"]:
+        ou = None
+        if u is not None:
+            ou = orc.Uniforms.from_buffer_copy(bytes(u))
+        o.draw(kind, clip, vary, col, ou)
+    return o.fb, o.z, o.stats
+
+
+def run_gpu(case, strip=None, split=None):
+    """Render a case through the C ABI on the GPU; split=k submits each draw in k flushes."""
+    from tinyrenderder_amd.api import Context
+    with Context(case["width"], case["height"], case["bpp"]) as ctx:
+        ctx.set_viewport(case["viewport"])
+        ctx.clear(case["clear"], case["zclear"])
+        if strip is not None:
+            ctx.set_strip(*strip)
+        for slot, t in case["textures"].items():
+            ctx.upload_texture(slot, t)
+        for kind, u, clip, vary, col in case["draws"]:
+            n = clip.shape[0]
+            parts = 1 if not split else split
+            edges = [n * i // parts for i in range(parts + 1)]
+            for a, b in zip(edges[:-1], edges[1:]):
+                if a == b:
+                    continue
+                ctx.draw(kind, clip[a:b], None if vary is None else vary[a:b], None if col is None else col[a:b], u)
+                if split:
+                    ctx.flush()
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+        line = ctx.stats_line()
+    return fb, z, st, line

@@ -1,0 +1,273 @@
+"""Python host mirror of the C ABI in include/trgl.h (ctypes over tinyrenderder_amd/libtrgl.so).
+
+This is the product path: it never falls back to a CPU implementation.  If the HIP library is
+missing or a call fails, it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtrgl.so")
+
+FLAT, GOURAUD, PHONG, EYE = 0, 1, 2, 3
+VARY = {FLAT: 0, GOURAUD: 3, PHONG: 24, EYE: 24}
+MEM_HOST, MEM_DEVICE = 0, 1
+PHASE_SETUP, PHASE_BIN, PHASE_RASTER, PHASE_TOTAL = 0, 1, 2, 3
+MAX_TEXTURES = 16
+
+# every symbol include/trgl.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "trgl_create", "trgl_destroy", "trgl_last_error", "trgl_set_viewport", "trgl_init_viewport", "trgl_clear",
+    "trgl_upload_texture", "trgl_set_strip", "trgl_draw", "trgl_flush", "trgl_sync", "trgl_read_framebuffer",
+    "trgl_write_framebuffer", "trgl_read_zbuffer", "trgl_write_zbuffer", "trgl_get_stats", "trgl_reset_stats",
+    "trgl_format_stats", "trgl_framebuffer_device_ptr", "trgl_zbuffer_device_ptr", "trgl_stream",
+    "trgl_set_profiling", "trgl_get_phase_ms", "trgl_reset_phase_ms", "trgl_get_last_flush_info",
+]
+
+
+class Uniforms(C.Structure):
+    """trgl_uniforms"""
+    _fields_ = [("model_view", C.c_double * 16), ("key_light_dir_eye", C.c_double * 3),
+                ("fill_light_dir_eye", C.c_double * 3), ("rim_light_dir_eye", C.c_double * 3),
+                ("normal_map_strength", C.c_double), ("tex_diffuse", C.c_int32), ("tex_normal", C.c_int32),
+                ("tex_specular", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    """trgl_stats"""
+    _fields_ = [("triangles_rasterized", C.c_uint64), ("fragments_drawn", C.c_uint64),
+                ("min_x", C.c_int32), ("min_y", C.c_int32), ("max_x", C.c_int32), ("max_y", C.c_int32),
+                ("min_z", C.c_double), ("max_z", C.c_double)]
+
+    def astuple(self):
+        return (self.triangles_rasterized, self.fragments_drawn, self.min_x, self.min_y, self.max_x, self.max_y,
+                self.min_z, self.max_z)
+
+
+def make_uniforms(model_view=None, key=(0, 0, 1), fill=(0, 0, 1), rim=(0, 0, 1), normal_map_strength=1.0,
+                  tex_diffuse=-1, tex_normal=-1, tex_specular=-1) -> Uniforms:
+    u = Uniforms()
+    mv = np.eye(4) if model_view is None else np.asarray(model_view, np.float64)
+    u.model_view[:] = mv.reshape(16).tolist()
+    u.key_light_dir_eye[:] = list(map(float, key))
+    u.fill_light_dir_eye[:] = list(map(float, fill))
+    u.rim_light_dir_eye[:] = list(map(float, rim))
+    u.normal_map_strength = float(normal_map_strength)
+    u.tex_diffuse, u.tex_normal, u.tex_specular, u.reserved = tex_diffuse, tex_normal, tex_specular, 0
+    return u
+
+
+class TrglError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """Load libtrgl.so and declare every prototype.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise TrglError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(path)
+    vp, u64p, dp = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)
+    L.trgl_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.trgl_destroy.argtypes = [vp]
+    L.trgl_last_error.argtypes = [vp]; L.trgl_last_error.restype = C.c_char_p
+    L.trgl_set_viewport.argtypes = [vp, dp]
+    L.trgl_init_viewport.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.trgl_clear.argtypes = [vp, C.c_void_p, C.c_double]
+    L.trgl_upload_texture.argtypes = [vp, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.trgl_set_strip.argtypes = [vp, C.c_int, C.c_int]
+    L.trgl_draw.argtypes = [vp, C.c_int, C.POINTER(Uniforms), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+    L.trgl_flush.argtypes = [vp]
+    L.trgl_sync.argtypes = [vp]
+    L.trgl_read_framebuffer.argtypes = [vp, C.c_void_p]
+    L.trgl_write_framebuffer.argtypes = [vp, C.c_void_p]
+    L.trgl_read_zbuffer.argtypes = [vp, C.c_void_p]
+    L.trgl_write_zbuffer.argtypes = [vp, C.c_void_p]
+    L.trgl_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.trgl_reset_stats.argtypes = [vp]
+    L.trgl_format_stats.argtypes = [C.POINTER(Stats), C.c_char_p, C.c_size_t]
+    for name in ("trgl_framebuffer_device_ptr", "trgl_zbuffer_device_ptr", "trgl_stream"):
+        getattr(L, name).argtypes = [vp]; getattr(L, name).restype = C.c_void_p
+    L.trgl_set_profiling.argtypes = [vp, C.c_int]
+    L.trgl_get_phase_ms.argtypes = [vp, dp, u64p]
+    L.trgl_reset_phase_ms.argtypes = [vp]
+    L.trgl_get_last_flush_info.argtypes = [vp, u64p, u64p, u64p]
+    for name in SYMBOLS:
+        f = getattr(L, name)
+        if f.restype is C.c_int and name not in ("trgl_last_error",):
+            f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    """host numpy array, or an object with a device pointer (torch tensor / int)."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    return a.ctypes.data
+
+
+class Context:
+    """One rasterizer context on one GPU — the reference's globals (Viewport, zbuffer, counters,
+    our_gl.cpp:12-22) plus the framebuffer TGAImage, as an object."""
+
+    def __init__(self, width: int, height: int, bpp: int = 3, device: int = 0):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        rc = self.L.trgl_create(device, width, height, bpp, C.byref(self.h))
+        if rc != 0:
+            raise TrglError(f"trgl_create failed ({rc}): {self.L.trgl_last_error(None).decode()}")
+        self.width, self.height, self.bpp, self.device = width, height, bpp, device
+        self._keep = []
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise TrglError(f"trgl call failed ({rc}): {self.L.trgl_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.L.trgl_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- state ----
+    def set_viewport(self, m):
+        m = np.ascontiguousarray(m, np.float64).reshape(16)
+        self._chk(self.L.trgl_set_viewport(self.h, m.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def init_viewport(self, x, y, w, h):
+        self._chk(self.L.trgl_init_viewport(self.h, x, y, w, h))
+
+    def clear(self, bgra=None, z=np.inf):
+        b = None if bgra is None else np.asarray(bgra, np.uint8)
+        self._chk(self.L.trgl_clear(self.h, None if b is None else b.ctypes.data, float(z)))
+
+    def upload_texture(self, slot, texels):
+        t = np.ascontiguousarray(texels, np.uint8)
+        if t.ndim == 2:
+            t = t[..., None]
+        self._chk(self.L.trgl_upload_texture(self.h, slot, t.ctypes.data, t.shape[1], t.shape[0], t.shape[2]))
+
+    def set_strip(self, y0, y1):
+        self._chk(self.L.trgl_set_strip(self.h, y0, y1))
+
+    # ---- submission ----
+    def draw(self, kind, clip, varyings=None, colors=None, uniforms=None, n=None, device=False):
+        """Host arrays (numpy) are copied before return; with device=True pass torch CUDA tensors (or raw
+        pointers with n) that stay alive until the flush has completed."""
+        K = VARY[kind]
+        if not device:
+            clip = np.ascontiguousarray(clip, np.float64)
+            n = clip.shape[0] if n is None else n
+            if K:
+                varyings = np.ascontiguousarray(varyings, np.float64)
+                assert varyings.shape == (n, K), varyings.shape
+            if colors is not None:
+                colors = np.ascontiguousarray(colors, np.uint32)
+                assert colors.shape == (n,)
+        else:
+            assert n is not None or hasattr(clip, "shape")
+            n = clip.shape[0] if n is None else n
+            self._keep.append((clip, varyings, colors))
+        self._chk(self.L.trgl_draw(self.h, kind, None if uniforms is None else C.byref(uniforms), _ptr(clip),
+                                   _ptr(varyings) if K else None, _ptr(colors), int(n), MEM_DEVICE if device else MEM_HOST))
+
+    def flush(self):
+        self._chk(self.L.trgl_flush(self.h))
+
+    def sync(self):
+        self._chk(self.L.trgl_sync(self.h))
+        self._keep.clear()
+
+    # ---- results ----
+    def read_framebuffer(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, self.bpp), np.uint8)
+        self._chk(self.L.trgl_read_framebuffer(self.h, out.ctypes.data))
+        self._keep.clear()
+        return out
+
+    def read_zbuffer(self) -> np.ndarray:
+        out = np.empty((self.height, self.width), np.float64)
+        self._chk(self.L.trgl_read_zbuffer(self.h, out.ctypes.data))
+        self._keep.clear()
+        return out
+
+    def write_framebuffer(self, fb):
+        fb = np.ascontiguousarray(fb, np.uint8)
+        assert fb.size == self.width * self.height * self.bpp
+        self._chk(self.L.trgl_write_framebuffer(self.h, fb.ctypes.data))
+
+    def write_zbuffer(self, z):
+        z = np.ascontiguousarray(z, np.float64)
+        assert z.size == self.width * self.height
+        self._chk(self.L.trgl_write_zbuffer(self.h, z.ctypes.data))
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.L.trgl_get_stats(self.h, C.byref(s)))
+        return s.astuple()
+
+    def stats_line(self) -> str:
+        s = Stats()
+        self._chk(self.L.trgl_get_stats(self.h, C.byref(s)))
+        buf = C.create_string_buffer(256)
+        self._chk(self.L.trgl_format_stats(C.byref(s), buf, 256))
+        return buf.value.decode().strip()
+
+    def reset_stats(self):
+        self._chk(self.L.trgl_reset_stats(self.h))
+
+    @property
+    def framebuffer_ptr(self) -> int:
+        return self.L.trgl_framebuffer_device_ptr(self.h)
+
+    @property
+    def zbuffer_ptr(self) -> int:
+        return self.L.trgl_zbuffer_device_ptr(self.h)
+
+    @property
+    def stream(self) -> int:
+        return self.L.trgl_stream(self.h)
+
+    # ---- measurement ----
+    def set_profiling(self, on: bool):
+        self._chk(self.L.trgl_set_profiling(self.h, 1 if on else 0))
+
+    def phase_ms(self):
+        ms = (C.c_double * 4)()
+        n = C.c_uint64()
+        self._chk(self.L.trgl_get_phase_ms(self.h, ms, C.byref(n)))
+        return list(ms), n.value
+
+    def reset_phase_ms(self):
+        self._chk(self.L.trgl_reset_phase_ms(self.h))
+
+    def last_flush_info(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self.L.trgl_get_last_flush_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(triangles=a.value, pairs=b.value, tiles=c.value)

@@ -1,0 +1,338 @@
+// kernels_bin.hip — per-triangle setup and the order-preserving binning prepass (gfx950).
+//
+//   setup      : our_gl.cpp:89-141 for every triangle -> TriRec + number of tiles overlapped
+//   scan       : exclusive scan (counts -> pair offsets; radix histograms -> scatter bases)
+//   expand     : (tile id, triangle id) pairs in triangle order
+//   radix pass : stable LSD counting sort of the pairs by tile id, so every tile's slice lists its
+//                triangles in SUBMISSION ORDER (z ties keep the earlier triangle, our_gl.cpp:165;
+//                fragments_drawn / z-range are order dependent, our_gl.cpp:194-198)
+//   bounds     : per-tile [start,end) in the sorted pair list
+//
+// All integer / fp64 IEEE work; built with -ffp-contract=off so no product is fused into a sum.
+#include <hip/hip_runtime.h>
+#include "trgl_device.h"
+#include "launch.h"
+
+namespace {
+
+__device__ __forceinline__ int x86_cvttsd2si(double d) {
+    // (int)double exactly as the reference's x86-64 build executes it: out of range -> INT_MIN
+    if (!(d > -2147483649.0 && d < 2147483648.0)) return INT_MIN;
+    return (int)d;
+}
+__device__ __forceinline__ double dmin3(double a, double b, double c) { double m = a; if (b < m) m = b; if (c < m) m = c; return m; }
+__device__ __forceinline__ double dmax3(double a, double b, double c) { double m = a; if (m < b) m = b; if (m < c) m = c; return m; }
+__device__ __forceinline__ double dot4(const double* m, const double* v) {
+    double sum = 0;                               // geometry.h:122-127: left to right from 0
+    sum += m[0] * v[0]; sum += m[1] * v[1]; sum += m[2] * v[2]; sum += m[3] * v[3];
+    return sum;
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+    for (int o = 32; o; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+    for (int o = 32; o; o >>= 1) { int t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// setup: one thread per triangle of one draw.  Follows our_gl.cpp:89-141 line by line.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_setup(FrameParams fp, const DrawDesc* __restrict__ draws, int draw_idx,
+                                               TriRec* __restrict__ recs, uint32_t* __restrict__ cnt,
+                                               uint2* __restrict__ tilebox, DevStats* __restrict__ stats) {
+    const DrawDesc& d = draws[draw_idx];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool in_range = i < d.n;
+    int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;   // contribution to bbox stats
+    uint32_t ntiles = 0;
+    uint2 tb = make_uint2(0, 0);
+    if (in_range) {
+        const double* c = d.clip + (size_t)i * 12;
+        double v[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[k] = c[k];
+        bool ok = !(v[3] <= 1e-12 || v[7] <= 1e-12 || v[11] <= 1e-12);                     // :94 (:97 is dead)
+        double ndc[12];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ndc[4 * q + k] = v[4 * q + k] / v[4 * q + 3];      // :101
+        bool zo0 = (ndc[2] < -1.0 || ndc[2] > 1.0), zo1 = (ndc[6] < -1.0 || ndc[6] > 1.0),
+             zo2 = (ndc[10] < -1.0 || ndc[10] > 1.0);
+        ok = ok && !(zo0 && zo1 && zo2);                                                   // :103-106
+#pragma unroll
+        for (int k = 0; k < 12; ++k) ok = ok && __builtin_isfinite(ndc[k]);                // :109-114
+        double sx[3], sy[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { sx[q] = dot4(fp.vp, ndc + 4 * q); sy[q] = dot4(fp.vp + 4, ndc + 4 * q); }  // :117-121
+        double e1x = sx[1] - sx[0], e1y = sy[1] - sy[0], e2x = sx[2] - sx[0], e2y = sy[2] - sy[0];
+        double cross_product = e1x * e2y - e1y * e2x;                                      // :124-126
+        ok = ok && !(cross_product <= 0);                                                  // :127
+        int min_x_px = max(0, x86_cvttsd2si(floor(dmin3(sx[0], sx[1], sx[2]))));           // :130-133
+        int max_x_px = min(fp.W - 1, x86_cvttsd2si(ceil(dmax3(sx[0], sx[1], sx[2]))));
+        int min_y_px = max(0, x86_cvttsd2si(floor(dmin3(sy[0], sy[1], sy[2]))));
+        int max_y_px = min(fp.H - 1, x86_cvttsd2si(ceil(dmax3(sy[0], sy[1], sy[2]))));
+        ok = ok && !(min_x_px > max_x_px || min_y_px > max_y_px);                          // :135
+        if (ok) {
+            bx0 = min_x_px; by0 = min_y_px; bx1 = max_x_px; by1 = max_y_px;                // :138-141
+            TriRec r;
+            r.ax = sx[0]; r.ay = sy[0];
+            r.s0x = sx[2] - sx[0]; r.s0y = sx[1] - sx[0];                                  // :78
+            r.s1x = sy[2] - sy[0]; r.s1y = sy[1] - sy[0];                                  // :79
+            r.uz = r.s0x * r.s1y - r.s0y * r.s1x;                                          // :80 (cross().z)
+            r.z0 = ndc[2]; r.z1 = ndc[6]; r.z2 = ndc[10];
+            r.iw0 = (fabs(v[3]) > 1e-12) ? (1.0 / v[3]) : 0.0;                             // :168-170
+            r.iw1 = (fabs(v[7]) > 1e-12) ? (1.0 / v[7]) : 0.0;
+            r.iw2 = (fabs(v[11]) > 1e-12) ? (1.0 / v[11]) : 0.0;
+            r.bx0 = (uint16_t)bx0; r.by0 = (uint16_t)by0; r.bx1 = (uint16_t)bx1; r.by1 = (uint16_t)by1;
+            r.color = d.colors ? d.colors[i] : 0xffffffffu;
+            r.draw = (uint32_t)draw_idx; r.local = i;
+            recs[d.first + i] = r;
+            // barycentric() rejects every pixel when |u.z| < 1e-12 (our_gl.cpp:82-83): no pairs then.
+            // Rows outside this context's strip are not ours either.
+            int y_lo = max(by0, fp.strip_y0), y_hi = min(by1, fp.strip_y1 - 1);
+            if (!(fabs(r.uz) < 1e-12) && y_lo <= y_hi) {
+                uint32_t tx0 = bx0 >> TRGL_TILE_LOG2, tx1 = bx1 >> TRGL_TILE_LOG2;
+                uint32_t ty0 = y_lo >> TRGL_TILE_LOG2, ty1 = y_hi >> TRGL_TILE_LOG2;
+                ntiles = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+                tb = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
+            }
+        }
+        cnt[d.first + i] = ntiles;
+        tilebox[d.first + i] = tb;
+    }
+    // bbox stats (our_gl.cpp:138-141): one set of atomics per wave
+    int wx0 = wave_min_i(bx0), wy0 = wave_min_i(by0), wx1 = wave_max_i(bx1), wy1 = wave_max_i(by1);
+    if ((threadIdx.x & 63) == 0 && wx0 != INT_MAX) {
+        atomicMin(&stats->min_x, wx0); atomicMin(&stats->min_y, wy0);
+        atomicMax(&stats->max_x, wx1); atomicMax(&stats->max_y, wy1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive scan of uint32[n]: reduce per block -> spine -> apply.  SCAN_ELEMS per block.
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_PER_THREAD = 16;
+constexpr int SCAN_ELEMS = SCAN_THREADS * SCAN_PER_THREAD;
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(v, o); if (lane >= o) v += t; }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix, total in *total
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* smem /*[4]*/, uint32_t* total) {
+    uint32_t inc = wave_incl_scan(v);
+    int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 63) smem[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_THREADS / 64; ++k) { uint32_t s = smem[k]; if (k < w) base += s; tot += s; }
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const uint32_t* __restrict__ in, uint64_t n,
+                                                               uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t smem[4];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_ELEMS + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) if (base + k < n) s += in[base + k];
+    uint32_t tot;
+    block_excl_scan(s, smem, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of the block sums in place; grand total (64-bit) to *total64
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_spine(uint32_t* __restrict__ block_sums, uint32_t nblocks,
+                                                              unsigned long long* __restrict__ total64) {
+    __shared__ uint32_t smem[4];
+    unsigned long long running = 0;
+    for (uint32_t start = 0; start < nblocks; start += SCAN_THREADS) {
+        uint32_t idx = start + threadIdx.x;
+        uint32_t v = idx < nblocks ? block_sums[idx] : 0;
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(v, smem, &tot);
+        if (idx < nblocks) block_sums[idx] = (uint32_t)running + ex;
+        running += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total64) *total64 = running;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const uint32_t* __restrict__ in, uint64_t n,
+                                                              const uint32_t* __restrict__ block_bases,
+                                                              uint32_t* __restrict__ out) {
+    __shared__ uint32_t smem[4];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_ELEMS + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+    uint32_t v[SCAN_PER_THREAD], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+    uint32_t tot;
+    uint32_t run = block_excl_scan(s, smem, &tot) + block_bases[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// expand: triangle i owns pairs [off[i], off[i]+cnt[i]) = its tiles in row-major order.
+// Triangles with many tiles are written by the whole wave.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_expand(uint32_t n, int tiles_x, const uint32_t* __restrict__ cnt,
+                                                const uint32_t* __restrict__ off, const uint2* __restrict__ tilebox,
+                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t c = 0, o = 0; uint2 tb = make_uint2(0, 0);
+    if (i < n) { c = cnt[i]; if (c) { o = off[i]; tb = tilebox[i]; } }
+    constexpr uint32_t SMALL = 8;
+    if (c && c <= SMALL) {
+        uint32_t tx0 = tb.x & 0xffff, ty0 = tb.x >> 16, tx1 = tb.y & 0xffff;
+        uint32_t wdt = tx1 - tx0 + 1;
+        for (uint32_t k = 0; k < c; ++k) {
+            uint32_t ty = ty0 + k / wdt, tx = tx0 + k % wdt;
+            keys[o + k] = ty * tiles_x + tx; vals[o + k] = i;
+        }
+    }
+    unsigned long long big = __ballot(c > SMALL);
+    int lane = threadIdx.x & 63;
+    while (big) {
+        int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        uint32_t cc = __shfl(c, src), oo = __shfl(o, src), ii = __shfl(i, src);
+        uint32_t bx = __shfl(tb.x, src), by = __shfl(tb.y, src);
+        uint32_t tx0 = bx & 0xffff, ty0 = bx >> 16, tx1 = by & 0xffff;
+        uint32_t wdt = tx1 - tx0 + 1;
+        for (uint32_t k = lane; k < cc; k += 64) {
+            uint32_t ty = ty0 + k / wdt, tx = tx0 + k % wdt;
+            keys[oo + k] = ty * tiles_x + tx; vals[oo + k] = ii;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stable LSD radix pass on `bits` key bits at `shift`.  Each WAVE owns a contiguous chunk of
+// RADIX_CHUNK pairs and walks it in order, 64 pairs a step; ranks inside a step come from ballots,
+// so equal keys keep their input order (= triangle submission order).
+// hist layout: [digit][worker] so one exclusive scan yields every worker's base per digit.
+// ---------------------------------------------------------------------------------------------
+constexpr int RADIX_CHUNK = 2048;
+constexpr int RADIX_MAX_BITS = 8;
+
+__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, uint32_t P, int shift, int bits,
+                                                    uint32_t nworkers, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_cnt[4][1 << RADIX_MAX_BITS];
+    int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t worker = blockIdx.x * 4 + w;
+    uint32_t nb = 1u << bits, mask = nb - 1;
+    for (uint32_t b = lane; b < nb; b += 64) s_cnt[w][b] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (worker < nworkers) {
+        uint64_t beg = (uint64_t)worker * RADIX_CHUNK;
+        uint64_t end = beg + RADIX_CHUNK; if (end > P) end = P;
+        for (uint64_t p = beg + lane; p < end; p += 64) atomicAdd(&s_cnt[w][(keys[p] >> shift) & mask], 1u);
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t b = lane; b < nb; b += 64) hist[(size_t)b * nworkers + worker] = s_cnt[w][b];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                       uint32_t P, int shift, int bits, uint32_t nworkers,
+                                                       const uint32_t* __restrict__ base,
+                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t s_pos[4][1 << RADIX_MAX_BITS];
+    int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t worker = blockIdx.x * 4 + w;
+    if (worker >= nworkers) return;
+    uint32_t nb = 1u << bits, mask = nb - 1;
+    for (uint32_t b = lane; b < nb; b += 64) s_pos[w][b] = base[(size_t)b * nworkers + worker];
+    __builtin_amdgcn_wave_barrier();
+    uint64_t beg = (uint64_t)worker * RADIX_CHUNK;
+    uint64_t end = beg + RADIX_CHUNK; if (end > P) end = P;
+    unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint64_t p0 = beg; p0 < end; p0 += 64) {
+        uint64_t p = p0 + lane;
+        bool act = p < end;
+        uint32_t k = act ? keys_in[p] : 0, v = act ? vals_in[p] : 0;
+        uint32_t dgt = (k >> shift) & mask;
+        unsigned long long same = __ballot(act);
+        for (int b = 0; b < bits; ++b) {
+            unsigned long long bal = __ballot((dgt >> b) & 1u);
+            same &= ((dgt >> b) & 1u) ? bal : ~bal;
+        }
+        uint32_t rank = __popcll(same & lt);
+        uint32_t cur = act ? s_pos[w][dgt] : 0;
+        __builtin_amdgcn_wave_barrier();
+        if (act) {
+            uint32_t dst = cur + rank;
+            keys_out[dst] = k; vals_out[dst] = v;
+            if (rank == 0) s_pos[w][dgt] = cur + (uint32_t)__popcll(same);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bounds(const uint32_t* __restrict__ keys, uint32_t P,
+                                                uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_end) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    uint32_t k = keys[p];
+    if (p == 0 || keys[p - 1] != k) tile_start[k] = p;
+    if (p == P - 1 || keys[p + 1] != k) tile_end[k] = p + 1;
+}
+
+}  // namespace
+
+// ---- launchers ----------------------------------------------------------------------------------
+namespace trgl {
+
+void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc* draws_dev, int draw_idx, uint32_t n,
+                  TriRec* recs, uint32_t* cnt, uint2* tilebox, DevStats* stats) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_setup, dim3((n + 255) / 256), dim3(256), 0, s, fp, draws_dev, draw_idx, recs, cnt, tilebox, stats);
+}
+
+uint32_t scan_num_blocks(uint64_t n) { return (uint32_t)((n + SCAN_ELEMS - 1) / SCAN_ELEMS); }
+
+// out may alias in.  block_sums needs scan_num_blocks(n) entries.
+void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* block_sums,
+                           unsigned long long* total64) {
+    if (!n) { if (total64) (void)hipMemsetAsync(total64, 0, 8, s); return; }
+    uint32_t nb = scan_num_blocks(n);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, block_sums);
+    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(SCAN_THREADS), 0, s, block_sums, nb, total64);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, block_sums, out);
+}
+
+void launch_expand(hipStream_t s, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* off,
+                   const uint2* tilebox, uint32_t* keys, uint32_t* vals) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_expand, dim3((n + 255) / 256), dim3(256), 0, s, n, tiles_x, cnt, off, tilebox, keys, vals);
+}
+
+uint32_t radix_num_workers(uint32_t P) { return (P + RADIX_CHUNK - 1) / RADIX_CHUNK; }
+
+void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+                       uint32_t* vals_out, uint32_t P, int shift, int bits, uint32_t* hist, uint32_t* scan_tmp) {
+    if (!P) return;
+    uint32_t nw = radix_num_workers(P);
+    uint32_t nblk = (nw + 3) / 4;
+    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(256), 0, s, keys_in, P, shift, bits, nw, hist);
+    launch_exclusive_scan(s, hist, hist, (uint64_t)nw << bits, scan_tmp, nullptr);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(256), 0, s, keys_in, vals_in, P, shift, bits, nw, hist,
+                       keys_out, vals_out);
+}
+
+void launch_bounds(hipStream_t s, const uint32_t* keys, uint32_t P, uint32_t* tile_start, uint32_t* tile_end) {
+    if (!P) return;
+    hipLaunchKernelGGL(k_bounds, dim3((P + 255) / 256), dim3(256), 0, s, keys, P, tile_start, tile_end);
+}
+
+}  // namespace trgl

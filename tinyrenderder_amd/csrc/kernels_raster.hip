@@ -1,0 +1,365 @@
+// kernels_raster.hip — the tile rasterizer (gfx950): bounding-box scan, barycentric coverage test,
+// fp64 z-test and the fragment shader of our_gl.cpp:147-199, one WAVEFRONT per 32x32 screen tile.
+//
+// The tile's z-buffer (fp64) and colour (packed BGRA) live in LDS for the whole tile, so the
+// compare-and-write of our_gl.cpp:165,191-192 needs no atomics: one wave walks the tile's triangle
+// list in submission order and, within one triangle, every lane owns a different pixel.  The tile
+// leaves the chip once, with row-contiguous stores.
+//
+// Arithmetic is the reference's, operation for operation, in fp64 with contraction off; the three
+// IEEE divisions per pixel of barycentric() (our_gl.cpp:85) are kept because the `>= 0` coverage
+// test and the written z depend on their rounding.
+#include <hip/hip_runtime.h>
+#include "trgl_device.h"
+#include "launch.h"
+
+namespace {
+
+__device__ __forceinline__ double dmax(double a, double b) { return (a < b) ? b : a; }   // std::max
+__device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; }   // std::min
+__device__ __forceinline__ int iclamp(int v, int lo, int hi) { return (v < lo) ? lo : (hi < v) ? hi : v; }
+__device__ __forceinline__ int x86_cvttsd2si(double d) {
+    if (!(d > -2147483649.0 && d < 2147483648.0)) return INT_MIN;
+    return (int)d;
+}
+__device__ __forceinline__ double dot3(const double* a, const double* b) {
+    double sum = 0; sum += a[0] * b[0]; sum += a[1] * b[1]; sum += a[2] * b[2]; return sum;   // geometry.h:122-127
+}
+__device__ __forceinline__ void normalized3(const double* v, double* out) {                   // geometry.h:136-140
+    double length = sqrt(dot3(v, v));
+    if (length == 0) { out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; return; }
+    out[0] = v[0] / length; out[1] = v[1] / length; out[2] = v[2] / length;
+}
+__device__ __forceinline__ unsigned long long zkey(double d) {       // order-preserving u64 key of a double
+    unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// ---- samplers: model.cpp:415-459 + TGAImage::get tgaimage.cpp:24-30 ----------------------------
+struct Color { uint32_t bgra; int bytespp; };   // TGAColor (tgaimage.h:29-31), bgra[0] in the low byte
+
+__device__ __forceinline__ const DevTexture* tex_slot(const DevTexture* tex, int slot) {
+    if (slot < 0 || slot >= TRGL_MAX_TEXTURES) return nullptr;
+    if (!tex[slot].data || tex[slot].w <= 0) return nullptr;
+    return &tex[slot];
+}
+__device__ __forceinline__ Color tex_fetch(const DevTexture* t, const double* uv) {
+    int x = iclamp(x86_cvttsd2si(uv[0] * t->w), 0, t->w - 1);
+    int y = iclamp(x86_cvttsd2si(uv[1] * t->h), 0, t->h - 1);
+    const uint8_t* p = t->data + ((size_t)x + (size_t)y * t->w) * t->bpp;
+    uint32_t v = 0;
+    for (int i = 0; i < t->bpp; ++i) v |= (uint32_t)p[i] << (8 * i);      // TGAColor(p,bpp): rest = 0
+    return Color{ v, t->bpp };
+}
+__device__ __forceinline__ void interp(const double* v0, const double* v1, const double* v2, const double* b, int n, double* out) {
+    for (int i = 0; i < n; ++i) out[i] = (v0[i] * b[0] + v1[i] * b[1]) + v2[i] * b[2];       // main.cpp:94-104
+}
+__device__ __forceinline__ double spec_pow(double x, double y) {
+    // std::pow(x, 1.0) == x exactly; PhongShader's exponent is always 1.0
+    return (y == 1.0) ? x : pow(x, y);
+}
+
+// PhongShader::fragment — main.cpp:92-170
+__device__ Color frag_phong(const trgl_uniforms& u, const DevTexture* tx, const double* vary, const double* b) {
+    const double* uvv = vary; const double* pos = vary + 6; const double* nrm = vary + 15;
+    double position_eye[3], geometry_normal[3], uv[2];
+    interp(pos, pos + 3, pos + 6, b, 3, position_eye);
+    interp(nrm, nrm + 3, nrm + 6, b, 3, geometry_normal);
+    interp(uvv, uvv + 2, uvv + 4, b, 2, uv);
+
+    const DevTexture* td = tex_slot(tx, u.tex_diffuse);
+    Color base = td ? tex_fetch(td, uv) : Color{ 0xffffffffu, 4 };                           // model.cpp:415-426
+    const DevTexture* ts = tex_slot(tx, u.tex_specular);
+    float specf = ts ? (float)(int)(tex_fetch(ts, uv).bgra & 0xff) / 255.0f : 1.0f;           // model.cpp:447-459
+    double specular_power = dmax(1.0, (double)specf);
+
+    int bsum = (int)(base.bgra & 0xff) + (int)((base.bgra >> 8) & 0xff) + (int)((base.bgra >> 16) & 0xff);
+    double brightness = bsum / (3.0 * 255.0);
+    bool is_eye_pixel = (brightness >= 0.85) && (specular_power <= 5.0);
+
+    double nmv[3] = { 0, 0, 1 };                                                              // model.cpp:428-445
+    const DevTexture* tn = tex_slot(tx, u.tex_normal);
+    if (tn) {
+        Color c = tex_fetch(tn, uv);
+        double n[3];
+        n[0] = (double)((c.bgra >> 16) & 0xff) / 255.0 * 2.0 - 1.0;
+        n[1] = (double)((c.bgra >> 8) & 0xff) / 255.0 * 2.0 - 1.0;
+        n[2] = (double)(c.bgra & 0xff) / 255.0 * 2.0 - 1.0;
+        normalized3(n, nmv);
+    }
+    double nme[3];                                                                            // main.cpp:116-119
+    for (int r = 0; r < 3; ++r) {
+        const double* m = u.model_view + 4 * r;
+        double sum = 0; sum += m[0] * nmv[0]; sum += m[1] * nmv[1]; sum += m[2] * nmv[2]; sum += m[3] * 0.0;
+        nme[r] = sum;
+    }
+    double N[3];
+    if (is_eye_pixel) { N[0] = geometry_normal[0]; N[1] = geometry_normal[1]; N[2] = geometry_normal[2]; }
+    else {
+        double s = u.normal_map_strength, mix[3];
+        for (int i = 0; i < 3; ++i) mix[i] = geometry_normal[i] * (1.0 - s) + nme[i] * s;
+        normalized3(mix, N);
+    }
+    double negp[3], V[3];
+    for (int i = 0; i < 3; ++i) negp[i] = position_eye[i] * -1.0;
+    normalized3(negp, V);
+
+    const double* Lk = u.key_light_dir_eye;
+    double key_diffuse = dmax(0.0, dot3(N, Lk)) * 1.0;
+    double k2 = 2.0 * dot3(N, Lk), rr[3], R[3];
+    for (int i = 0; i < 3; ++i) rr[i] = N[i] * k2 - Lk[i];
+    normalized3(rr, R);
+    double rvd = dmax(0.0, dot3(R, V));
+    double key_specular = (rvd > 0.0 ? spec_pow(rvd, specular_power) : 0.0) * 1.0;
+    double fill_diffuse = dmax(0.0, dot3(N, u.fill_light_dir_eye)) * 0.35;
+    double rim_diffuse = dmax(0.0, dot3(N, u.rim_light_dir_eye)) * 0.6;
+    double total_diffuse = key_diffuse + fill_diffuse + rim_diffuse;
+    double total_specular = key_specular;
+    double ambient = 0.10;
+
+    uint32_t out = base.bgra & 0xff000000u;
+    for (int ch = 0; ch < 3; ++ch) {
+        double channel_value = (double)((base.bgra >> (8 * ch)) & 0xff);
+        double final_value = channel_value * (ambient + total_diffuse) + 255.0 * (0.35 * total_specular);
+        out |= (uint32_t)(unsigned char)dmin(255.0, final_value) << (8 * ch);
+    }
+    return Color{ out, base.bytespp };
+}
+
+// EyeShader::fragment — main.cpp:220-261
+__device__ Color frag_eye(const trgl_uniforms& u, const DevTexture* tx, const double* vary, const double* b) {
+    const double* uvv = vary; const double* pos = vary + 6; const double* nrm = vary + 15;
+    double position_eye[3], ni[3], N[3], uv[2];
+    interp(pos, pos + 3, pos + 6, b, 3, position_eye);
+    interp(nrm, nrm + 3, nrm + 6, b, 3, ni);
+    normalized3(ni, N);
+    interp(uvv, uvv + 2, uvv + 4, b, 2, uv);
+
+    const DevTexture* td = tex_slot(tx, u.tex_diffuse);
+    Color base = td ? tex_fetch(td, uv) : Color{ 0xffffffffu, 4 };
+    double negp[3], V[3];
+    for (int i = 0; i < 3; ++i) negp[i] = position_eye[i] * -1.0;
+    normalized3(negp, V);
+
+    const double* Lk = u.key_light_dir_eye;
+    double key_diffuse = dmax(0.0, dot3(N, Lk)) * 1.0;
+    double rim_diffuse = dmax(0.0, dot3(N, u.rim_light_dir_eye)) * 0.6;
+    double total_diffuse = key_diffuse + rim_diffuse;
+
+    const DevTexture* ts = tex_slot(tx, u.tex_specular);
+    float specf = ts ? (float)(int)(tex_fetch(ts, uv).bgra & 0xff) / 255.0f : 1.0f;
+    double specular_power = dmax(1.0, (double)specf) * 8.0;
+    double k2 = 2.0 * dot3(N, Lk), rr[3], R[3];
+    for (int i = 0; i < 3; ++i) rr[i] = N[i] * k2 - Lk[i];
+    normalized3(rr, R);
+    double rvd = dmax(0.0, dot3(R, V));
+    double specular = (rvd > 0.0 ? spec_pow(rvd, specular_power) : 0.0);
+
+    uint32_t out = base.bgra & 0xff000000u;
+    for (int ch = 0; ch < 3; ++ch) {
+        double channel_value = (double)((base.bgra >> (8 * ch)) & 0xff);
+        double final_value = channel_value * (0.1 + total_diffuse) + 255.0 * (1.5 * specular);
+        out |= (uint32_t)(unsigned char)dmin(255.0, final_value) << (8 * ch);
+    }
+    return Color{ out, base.bytespp };
+}
+
+// GOURAUD: base * (float)(i0*b0 + i1*b1 + i2*b2), TGAColor::operator*(float) tgaimage.h:55-62
+__device__ __forceinline__ uint32_t frag_gouraud(uint32_t base, const double* vary, const double* b) {
+    double id = (vary[0] * b[0] + vary[1] * b[1]) + vary[2] * b[2];
+    float intensity = (float)id;
+    if (intensity < 0.f) intensity = 0.f;
+    if (intensity > 1.f) intensity = 1.f;
+    uint32_t out = 0;
+    for (int i = 0; i < 4; ++i) {
+        float c = (float)(int)((base >> (8 * i)) & 0xff) * intensity;
+        out |= (uint32_t)(uint8_t)c << (8 * i);
+    }
+    return out;
+}
+
+// LDS index of pixel (x,y) of the tile: rows are XOR-swizzled in 8-pixel groups so that the 8x8
+// pixel block a wave touches per step (4 rows per 32-lane group) is bank-conflict free for both the
+// 8-byte z reads and the 4-byte colour reads.
+__device__ __forceinline__ int lds_index(int x, int y) {
+    return ((y & (TRGL_TILE - 1)) << TRGL_TILE_LOG2) + ((x & (TRGL_TILE - 1)) ^ ((y & 3) << 3));
+}
+
+template <bool FLAT_ONLY>
+__global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
+                                                const uint32_t* __restrict__ vals,
+                                                const uint32_t* __restrict__ tile_start,
+                                                const uint32_t* __restrict__ tile_end,
+                                                const DrawDesc* __restrict__ draws,
+                                                const DevTexture* __restrict__ tex, DevStats* __restrict__ stats) {
+    __shared__ double   s_z[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
+    __shared__ uint32_t s_c[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile_x = blockIdx.x * TRGL_WAVES_PER_BLOCK + w;
+    const int tile_y = fp.strip_ty0 + blockIdx.y;
+    if (tile_x >= fp.tiles_x) return;                    // no block-level barrier is used below
+    const int t = tile_y * fp.tiles_x + tile_x;
+    const int px0 = tile_x << TRGL_TILE_LOG2, py0 = tile_y << TRGL_TILE_LOG2;
+    // rows / columns of this tile that exist and belong to this context's strip
+    const int xa1 = min(px0 + TRGL_TILE - 1, fp.W - 1);
+    const int ya0 = max(py0, fp.strip_y0), ya1 = min(min(py0 + TRGL_TILE - 1, fp.H - 1), fp.strip_y1 - 1);
+
+    uint32_t beg = tile_start[t], end = tile_end[t];
+    if (!fp.init_from_clear && beg == end) return;       // nothing to composite onto this tile
+
+    double* zt = s_z[w];
+    uint32_t* ct = s_c[w];
+
+    // ---- tile in: clear values, or the current framebuffer / z-buffer contents --------------------
+    if (fp.init_from_clear) {
+        for (int k = lane; k < TRGL_TILE_PIX; k += 64) { zt[k] = fp.clear_z; ct[k] = fp.clear_color; }
+    } else {
+        for (int r = 0; r < TRGL_TILE; r += 2) {
+            int x = px0 + (lane & 31), y = py0 + r + (lane >> 5);
+            double z = fp.clear_z; uint32_t c = 0;
+            if (x <= xa1 && y >= ya0 && y <= ya1) {
+                size_t idx = (size_t)x + (size_t)y * fp.W;
+                z = fp.zb[idx];
+                const uint8_t* p = fp.fb + idx * fp.bpp;
+                for (int i = 0; i < fp.bpp; ++i) c |= (uint32_t)p[i] << (8 * i);
+            }
+            int li = lds_index(x, y);
+            zt[li] = z; ct[li] = c;
+        }
+    }
+
+    uint32_t frags = 0;
+    double zmin = __builtin_inf(), zmax = -__builtin_inf();
+
+    // ---- the tile's triangles, in submission order --------------------------------------------
+    for (uint32_t p = beg; p < end; ++p) {
+        const uint32_t tri = __builtin_amdgcn_readfirstlane(vals[p]);
+        const TriRec& r = recs[tri];
+        const int x0 = max((int)r.bx0, px0), x1 = min((int)r.bx1, xa1);
+        const int y0 = max((int)r.by0, ya0), y1 = min((int)r.by1, ya1);
+        const double uz = r.uz;
+        for (int by = y0; by <= y1; by += 8) {
+            for (int bx = x0; bx <= x1; bx += 8) {
+                const int x = bx + (lane & 7), y = by + (lane >> 3);
+                const bool act = (x <= x1) && (y <= y1);
+                // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
+                const double pxc = (double)x + 0.5, pyc = (double)y + 0.5;        // :149
+                const double s0z = r.ax - pxc, s1z = r.ay - pyc;
+                const double ux = r.s0y * s1z - s0z * r.s1y;                      // geometry.h:145
+                const double uy = s0z * r.s1x - r.s0x * s1z;                      // geometry.h:146
+                const double b0 = 1.0 - (ux + uy) / uz;
+                const double b1 = uy / uz;
+                const double b2 = ux / uz;
+                bool cov = act && !(b0 < 0 || b1 < 0 || b2 < 0);                  // :152
+                const double z = b0 * r.z0 + b1 * r.z1 + b2 * r.z2;               // :156-158
+                cov = cov && __builtin_isfinite(z);                               // :160
+                if (__ballot(cov) == 0) continue;
+                const int li = lds_index(x, y);
+                const double zold = zt[li];
+                if (cov && (z < zold)) {                                          // :165
+                    uint32_t color;
+                    if (FLAT_ONLY) {
+                        color = r.color;
+                    } else {
+                        const DrawDesc& d = draws[r.draw];
+                        if (d.kind == TRGL_SHADER_FLAT) {
+                            color = r.color;
+                        } else {
+                            double bc[3] = { b0, b1, b2 }, pc[3];
+                            const double denom = b0 * r.iw0 + b1 * r.iw1 + b2 * r.iw2;   // :172-174
+                            if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }
+                            else { pc[0] = (bc[0] * r.iw0) / denom; pc[1] = (bc[1] * r.iw1) / denom; pc[2] = (bc[2] * r.iw2) / denom; }
+                            const double* vary = d.vary + (size_t)r.local * d.K;
+                            if (d.kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(r.color, vary, pc);
+                            else if (d.kind == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
+                            else color = frag_eye(d.u, tex, vary, pc).bgra;
+                        }
+                    }
+                    zt[li] = z;                                                   // :191
+                    ct[li] = color;                                               // :192
+                    ++frags;                                                      // :194
+                    zmin = dmin(zmin, z); zmax = dmax(zmax, z);                   // :197-198
+                }
+            }
+        }
+    }
+
+    // ---- tile out: row-contiguous stores --------------------------------------------------------
+    const bool full_x = (px0 + TRGL_TILE - 1) <= xa1;
+    // z: 16 B per lane, 4 rows per store instruction
+    if (full_x && (fp.W & 1) == 0) {
+        for (int r4 = 0; r4 < TRGL_TILE; r4 += 4) {
+            int x = px0 + ((lane & 15) << 1), y = py0 + r4 + (lane >> 4);
+            if (y >= ya0 && y <= ya1) {
+                double2 v = *reinterpret_cast<const double2*>(&zt[lds_index(x, y)]);
+                *reinterpret_cast<double2*>(&fp.zb[(size_t)x + (size_t)y * fp.W]) = v;
+            }
+        }
+    } else {
+        for (int r2 = 0; r2 < TRGL_TILE; r2 += 2) {
+            int x = px0 + (lane & 31), y = py0 + r2 + (lane >> 5);
+            if (x <= xa1 && y >= ya0 && y <= ya1) fp.zb[(size_t)x + (size_t)y * fp.W] = zt[lds_index(x, y)];
+        }
+    }
+    // colour: 4 pixels per lane (12 B for RGB, 16 B for RGBA), 8 rows per store instruction
+    if (full_x && (fp.W & 3) == 0 && (fp.bpp == 3 || fp.bpp == 4)) {
+        for (int r8 = 0; r8 < TRGL_TILE; r8 += 8) {
+            int x = px0 + ((lane & 7) << 2), y = py0 + r8 + (lane >> 3);
+            if (y >= ya0 && y <= ya1) {
+                uint4 c = *reinterpret_cast<const uint4*>(&ct[lds_index(x, y)]);
+                size_t idx = (size_t)x + (size_t)y * fp.W;
+                if (fp.bpp == 4) {
+                    *reinterpret_cast<uint4*>(fp.fb + idx * 4) = c;
+                } else {
+                    uint32_t d0 = (c.x & 0xffffffu) | (c.y << 24);
+                    uint32_t d1 = ((c.y >> 8) & 0xffffu) | (c.z << 16);
+                    uint32_t d2 = ((c.z >> 16) & 0xffu) | (c.w << 8);
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(fp.fb + idx * 3);
+                    dst[0] = d0; dst[1] = d1; dst[2] = d2;
+                }
+            }
+        }
+    } else {
+        for (int r2 = 0; r2 < TRGL_TILE; r2 += 2) {
+            int x = px0 + (lane & 31), y = py0 + r2 + (lane >> 5);
+            if (x <= xa1 && y >= ya0 && y <= ya1) {
+                uint32_t c = ct[lds_index(x, y)];
+                uint8_t* dst = fp.fb + ((size_t)x + (size_t)y * fp.W) * fp.bpp;
+                for (int i = 0; i < fp.bpp; ++i) dst[i] = (uint8_t)(c >> (8 * i));
+            }
+        }
+    }
+
+    // ---- stats: our_gl.cpp:194-198, reduced per wave, one set of atomics per tile -----------------
+    unsigned long long kmin = zkey(zmin), kmax = zkey(zmax);
+    for (int o = 32; o; o >>= 1) {
+        frags += __shfl_xor(frags, o);
+        unsigned long long a = __shfl_xor(kmin, o); kmin = a < kmin ? a : kmin;
+        unsigned long long b = __shfl_xor(kmax, o); kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0 && frags) {
+        atomicAdd(&stats->fragments, (unsigned long long)frags);
+        atomicMin(&stats->zmin_key, kmin);
+        atomicMax(&stats->zmax_key, kmax);
+    }
+}
+
+}  // namespace
+
+namespace trgl {
+
+void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const TriRec* recs, const uint32_t* vals,
+                   const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
+                   const DevTexture* tex, DevStats* stats) {
+    int rows = fp.strip_ty1 - fp.strip_ty0;
+    if (rows <= 0) return;
+    dim3 grid((fp.tiles_x + TRGL_WAVES_PER_BLOCK - 1) / TRGL_WAVES_PER_BLOCK, rows);
+    if (flat_only)
+        hipLaunchKernelGGL(k_raster<true>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats);
+    else
+        hipLaunchKernelGGL(k_raster<false>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats);
+}
+
+}  // namespace trgl

@@ -1,0 +1,28 @@
+// launch.h — host-callable launchers of the gfx950 kernels (kernels_bin.hip, kernels_raster.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "trgl_device.h"
+
+namespace trgl {
+
+void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc* draws_dev, int draw_idx, uint32_t n,
+                  TriRec* recs, uint32_t* cnt, uint2* tilebox, DevStats* stats);
+
+uint32_t scan_num_blocks(uint64_t n);
+void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* block_sums,
+                           unsigned long long* total64);
+
+void launch_expand(hipStream_t s, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* off,
+                   const uint2* tilebox, uint32_t* keys, uint32_t* vals);
+
+uint32_t radix_num_workers(uint32_t P);
+void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+                       uint32_t* vals_out, uint32_t P, int shift, int bits, uint32_t* hist, uint32_t* scan_tmp);
+
+void launch_bounds(hipStream_t s, const uint32_t* keys, uint32_t P, uint32_t* tile_start, uint32_t* tile_end);
+
+void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const TriRec* recs, const uint32_t* vals,
+                   const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
+                   const DevTexture* tex, DevStats* stats);
+
+}  // namespace trgl

@@ -1,0 +1,495 @@
+// trgl_api.cpp — host side of the C ABI in include/trgl.h: context, HBM buffers, the flush pipeline.
+//
+// A flush runs, on the context's own HIP stream:
+//   setup (per draw) -> scan(counts) -> expand -> stable radix passes by tile id -> bounds -> raster
+// and is the batched equivalent of the reference's per-face loop of rasterize() calls
+// (main.cpp:660-666): submission order is preserved per tile, so results are identical.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/trgl.h"
+#include "launch.h"
+#include "trgl_device.h"
+
+using namespace trgl;
+
+static thread_local std::string g_create_error;
+
+struct StageChunk { char* base; size_t cap, used; };
+
+struct trgl_ctx {
+    int device = 0;
+    int W = 0, H = 0, bpp = 0, tiles_x = 0, tiles_y = 0;
+    hipStream_t stream = nullptr;
+    uint8_t* fb = nullptr;
+    double* zb = nullptr;
+    double vp[16];
+    bool clear_pending = true;
+    uint32_t clear_color = 0xff000000u;
+    double clear_z = std::numeric_limits<double>::infinity();
+    int strip_y0 = 0, strip_y1 = 0;
+
+    DevTexture tex_host[TRGL_MAX_TEXTURES];
+    DevTexture* tex_dev = nullptr;
+
+    std::vector<DrawDesc> draws;
+    uint64_t queued_tris = 0;
+    std::vector<StageChunk> stage;
+
+    TriRec* recs = nullptr; uint32_t* cnt = nullptr; uint32_t* off = nullptr; uint2* tilebox = nullptr;
+    size_t cap_tris = 0;
+    uint32_t* keys[2] = { nullptr, nullptr }; uint32_t* vals[2] = { nullptr, nullptr };
+    size_t cap_pairs = 0;
+    uint32_t* hist = nullptr; size_t cap_hist = 0;
+    uint32_t* scan_tmp = nullptr; size_t cap_scan = 0;
+    uint32_t* tile_start = nullptr; uint32_t* tile_end = nullptr;
+    DrawDesc* draws_dev = nullptr;
+    DrawDesc* draws_pinned = nullptr;
+    DevStats* stats_dev = nullptr;
+    DevStats* stats_pinned = nullptr;
+
+    uint64_t triangles_total = 0;       // our_gl.cpp:90 counts every call, host side
+    uint64_t last_tris = 0, last_pairs = 0;
+
+    bool profiling = false, events_pending = false;
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    double phase_ms[TRGL_NUM_PHASES] = { 0, 0, 0, 0 };
+    uint64_t flushes_timed = 0;
+
+    std::string err;
+};
+
+#define HIPCHK(ctx, expr)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            return TRGL_E_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+#define CHKCTX(ctx) do { if (!(ctx)) return TRGL_E_INVALID; if (hipSetDevice((ctx)->device) != hipSuccess) return TRGL_E_HIP; } while (0)
+
+static int fail(trgl_ctx* c, int code, const char* msg) { c->err = msg; return code; }
+
+static unsigned long long zkey_host(double d) {
+    unsigned long long b; std::memcpy(&b, &d, 8);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+static double zkey_decode(unsigned long long k) {
+    unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double d; std::memcpy(&d, &b, 8); return d;
+}
+
+static int reset_dev_stats(trgl_ctx* c) {
+    DevStats s;
+    s.fragments = 0;
+    s.zmin_key = zkey_host(std::numeric_limits<double>::infinity());
+    s.zmax_key = zkey_host(-std::numeric_limits<double>::infinity());
+    s.min_x = INT32_MAX; s.min_y = INT32_MAX; s.max_x = INT32_MIN; s.max_y = INT32_MIN;
+    s.pairs_total = 0;
+    *c->stats_pinned = s;
+    HIPCHK(c, hipMemcpyAsync(c->stats_dev, c->stats_pinned, sizeof(DevStats), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TRGL_OK;
+}
+
+// (re)allocate a device buffer; the old contents are not kept
+static int realloc_dev(trgl_ctx* c, void** p, size_t bytes) {
+    if (*p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(*p)); *p = nullptr; }
+    HIPCHK(c, hipMalloc(p, bytes));
+    return TRGL_OK;
+}
+template <class T> static int grow(trgl_ctx* c, T*& p, size_t& cap, size_t need) {
+    if (need <= cap && p) return TRGL_OK;
+    size_t ncap = need + need / 4 + 1024;
+    int r = realloc_dev(c, (void**)&p, ncap * sizeof(T)); if (r) return r;
+    cap = ncap;
+    return TRGL_OK;
+}
+
+extern "C" {
+
+const char* trgl_last_error(const trgl_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int trgl_create(int device, int width, int height, int bpp, trgl_ctx** out) {
+    if (!out || width <= 0 || height <= 0 || width > 65535 || height > 65535 || !(bpp == 1 || bpp == 3 || bpp == 4)) {
+        g_create_error = "trgl_create: bad arguments (width/height in 1..65535, bpp in {1,3,4})";
+        return TRGL_E_INVALID;
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return TRGL_E_HIP; }
+    trgl_ctx* c = new trgl_ctx();
+    c->device = device; c->W = width; c->H = height; c->bpp = bpp;
+    c->tiles_x = (width + TRGL_TILE - 1) / TRGL_TILE;
+    c->tiles_y = (height + TRGL_TILE - 1) / TRGL_TILE;
+    c->strip_y0 = 0; c->strip_y1 = height;
+    std::memset(c->tex_host, 0, sizeof(c->tex_host));
+    size_t npx = (size_t)width * height, ntiles = (size_t)c->tiles_x * c->tiles_y;
+#define CRE(expr) do { hipError_t e2 = (expr); if (e2 != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e2); trgl_destroy(c); return TRGL_E_HIP; } } while (0)
+    CRE(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CRE(hipMalloc((void**)&c->fb, npx * bpp));
+    CRE(hipMalloc((void**)&c->zb, npx * sizeof(double)));
+    CRE(hipMalloc((void**)&c->tex_dev, sizeof(c->tex_host)));
+    CRE(hipMemset(c->tex_dev, 0, sizeof(c->tex_host)));
+    CRE(hipMalloc((void**)&c->tile_start, ntiles * 4));
+    CRE(hipMalloc((void**)&c->tile_end, ntiles * 4));
+    CRE(hipMalloc((void**)&c->draws_dev, sizeof(DrawDesc) * TRGL_MAX_DRAWS));
+    CRE(hipHostMalloc((void**)&c->draws_pinned, sizeof(DrawDesc) * TRGL_MAX_DRAWS));
+    CRE(hipMalloc((void**)&c->stats_dev, sizeof(DevStats)));
+    CRE(hipHostMalloc((void**)&c->stats_pinned, sizeof(DevStats)));
+    for (int i = 0; i < 4; ++i) CRE(hipEventCreate(&c->ev[i]));
+#undef CRE
+    // init_viewport(0,0,W,H), our_gl.cpp:59-69
+    trgl_init_viewport(c, 0, 0, width, height);
+    if (reset_dev_stats(c) != TRGL_OK) { g_create_error = c->err; trgl_destroy(c); return TRGL_E_HIP; }
+    *out = c;
+    return TRGL_OK;
+}
+
+int trgl_destroy(trgl_ctx* c) {
+    if (!c) return TRGL_E_INVALID;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& s : c->stage) (void)hipFree(s.base);
+    for (int i = 0; i < TRGL_MAX_TEXTURES; ++i) if (c->tex_host[i].data) (void)hipFree((void*)c->tex_host[i].data);
+    void* ptrs[] = { c->fb, c->zb, c->tex_dev, c->recs, c->cnt, c->off, c->tilebox, c->keys[0], c->keys[1], c->vals[0],
+                     c->vals[1], c->hist, c->scan_tmp, c->tile_start, c->tile_end, c->draws_dev, c->stats_dev };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->draws_pinned) (void)hipHostFree(c->draws_pinned);
+    if (c->stats_pinned) (void)hipHostFree(c->stats_pinned);
+    for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return TRGL_OK;
+}
+
+int trgl_set_viewport(trgl_ctx* c, const double m[16]) {
+    CHKCTX(c);
+    if (!m) return fail(c, TRGL_E_INVALID, "trgl_set_viewport: null matrix");
+    if (!c->draws.empty() && std::memcmp(c->vp, m, sizeof(c->vp)) != 0) {   // rasterize() reads Viewport at call time
+        int r = trgl_flush(c); if (r) return r;
+    }
+    std::memcpy(c->vp, m, sizeof(c->vp));
+    return TRGL_OK;
+}
+
+int trgl_init_viewport(trgl_ctx* c, int x, int y, int w, int h) {          // our_gl.cpp:59-69
+    if (!c) return TRGL_E_INVALID;
+    double m[16];
+    for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) m[4 * r + k] = (r == k) ? 1.0 : 0.0;
+    m[0] = w / 2.0; m[5] = h / 2.0; m[3] = x + w / 2.0; m[7] = y + h / 2.0; m[10] = 1.0; m[11] = 0.0;
+    if (c->stream == nullptr || c->draws.empty()) { std::memcpy(c->vp, m, sizeof(m)); return TRGL_OK; }
+    return trgl_set_viewport(c, m);
+}
+
+int trgl_clear(trgl_ctx* c, const uint8_t bgra[4], double z_clear) {
+    CHKCTX(c);
+    if (!c->draws.empty()) { int r = trgl_flush(c); if (r) return r; }      // earlier draws come first
+    static const uint8_t dflt[4] = { 0, 0, 0, 255 };                         // TGAColor(), tgaimage.h:33
+    const uint8_t* p = bgra ? bgra : dflt;
+    c->clear_color = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    c->clear_z = z_clear;
+    c->clear_pending = true;
+    return TRGL_OK;
+}
+
+int trgl_upload_texture(trgl_ctx* c, int slot, const uint8_t* texels, int w, int h, int bpp) {
+    CHKCTX(c);
+    if (slot < 0 || slot >= TRGL_MAX_TEXTURES) return fail(c, TRGL_E_INVALID, "trgl_upload_texture: bad slot");
+    if (!c->draws.empty()) { int r = trgl_flush(c); if (r) return r; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->tex_host[slot].data) { HIPCHK(c, hipFree((void*)c->tex_host[slot].data)); c->tex_host[slot] = DevTexture{ nullptr, 0, 0, 0, 0 }; }
+    if (texels && w > 0 && h > 0) {
+        if (!(bpp == 1 || bpp == 3 || bpp == 4)) return fail(c, TRGL_E_INVALID, "trgl_upload_texture: bpp must be 1, 3 or 4");
+        uint8_t* d = nullptr; size_t bytes = (size_t)w * h * bpp;
+        HIPCHK(c, hipMalloc((void**)&d, bytes));
+        HIPCHK(c, hipMemcpy(d, texels, bytes, hipMemcpyHostToDevice));
+        c->tex_host[slot] = DevTexture{ d, w, h, bpp, 0 };
+    }
+    HIPCHK(c, hipMemcpy(c->tex_dev, c->tex_host, sizeof(c->tex_host), hipMemcpyHostToDevice));
+    return TRGL_OK;
+}
+
+int trgl_set_strip(trgl_ctx* c, int y0, int y1) {
+    CHKCTX(c);
+    if (y0 < 0 || y1 > c->H || y0 > y1) return fail(c, TRGL_E_INVALID, "trgl_set_strip: need 0 <= y0 <= y1 <= H");
+    if (!c->draws.empty()) { int r = trgl_flush(c); if (r) return r; }
+    c->strip_y0 = y0; c->strip_y1 = y1;
+    return TRGL_OK;
+}
+
+static int vary_count(int kind) {
+    switch (kind) {
+    case TRGL_SHADER_GOURAUD: return TRGL_VARY_GOURAUD;
+    case TRGL_SHADER_PHONG: return TRGL_VARY_PHONG;
+    case TRGL_SHADER_EYE: return TRGL_VARY_EYE;
+    default: return 0;
+    }
+}
+
+// copy host data into the staging arena (device); chunks live until the flush that uses them is done
+static int stage_copy(trgl_ctx* c, const void* src, size_t bytes, void** dev) {
+    size_t need = (bytes + 255) & ~size_t(255);
+    StageChunk* ch = nullptr;
+    for (auto& s : c->stage) if (s.cap - s.used >= need) { ch = &s; break; }
+    if (!ch) {
+        StageChunk s; s.cap = need > (size_t(64) << 20) ? need : (size_t(64) << 20); s.used = 0; s.base = nullptr;
+        HIPCHK(c, hipMalloc((void**)&s.base, s.cap));
+        c->stage.push_back(s); ch = &c->stage.back();
+    }
+    *dev = ch->base + ch->used; ch->used += need;
+    HIPCHK(c, hipMemcpy(*dev, src, bytes, hipMemcpyHostToDevice));   // "copied before trgl_draw returns"
+    return TRGL_OK;
+}
+
+int trgl_draw(trgl_ctx* c, int kind, const trgl_uniforms* u, const double* clip, const double* vary,
+              const uint32_t* colors, uint64_t n, int mem_kind) {
+    CHKCTX(c);
+    if (kind < 0 || kind >= TRGL_NUM_SHADERS) return fail(c, TRGL_E_INVALID, "trgl_draw: unknown shader kind");
+    if (n == 0) return TRGL_OK;
+    if (!clip) return fail(c, TRGL_E_INVALID, "trgl_draw: clip is null");
+    int K = vary_count(kind);
+    if (K && !vary) return fail(c, TRGL_E_INVALID, "trgl_draw: this shader kind needs varyings");
+    if ((kind == TRGL_SHADER_PHONG || kind == TRGL_SHADER_EYE) && !u) return fail(c, TRGL_E_INVALID, "trgl_draw: PHONG/EYE need uniforms");
+    if (mem_kind != TRGL_MEM_HOST && mem_kind != TRGL_MEM_DEVICE) return fail(c, TRGL_E_INVALID, "trgl_draw: bad mem_kind");
+    if (c->queued_tris + n > 0xffffffffull) { int r = trgl_flush(c); if (r) return r; }
+    if (n > 0xffffffffull) return fail(c, TRGL_E_UNSUPPORTED, "trgl_draw: more than 2^32-1 triangles in one draw");
+    if (c->draws.size() >= TRGL_MAX_DRAWS) { int r = trgl_flush(c); if (r) return r; }
+
+    DrawDesc d; std::memset(&d, 0, sizeof(d));
+    d.n = (uint32_t)n; d.first = (uint32_t)c->queued_tris; d.kind = kind; d.K = K;
+    if (u) d.u = *u; else { d.u.tex_diffuse = d.u.tex_normal = d.u.tex_specular = -1; }
+    if (mem_kind == TRGL_MEM_DEVICE) {
+        d.clip = clip; d.vary = K ? vary : nullptr; d.colors = colors;
+    } else {
+        void* p = nullptr; int r;
+        if ((r = stage_copy(c, clip, n * 12 * sizeof(double), &p))) return r;
+        d.clip = (const double*)p;
+        if (K) { if ((r = stage_copy(c, vary, n * K * sizeof(double), &p))) return r; d.vary = (const double*)p; }
+        if (colors) { if ((r = stage_copy(c, colors, n * sizeof(uint32_t), &p))) return r; d.colors = (const uint32_t*)p; }
+    }
+    c->draws.push_back(d);
+    c->queued_tris += n;
+    return TRGL_OK;
+}
+
+static int resolve_events(trgl_ctx* c) {
+    if (!c->events_pending) return TRGL_OK;
+    HIPCHK(c, hipEventSynchronize(c->ev[3]));
+    float ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->phase_ms[TRGL_PHASE_SETUP] += ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->phase_ms[TRGL_PHASE_BIN] += ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->phase_ms[TRGL_PHASE_RASTER] += ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); c->phase_ms[TRGL_PHASE_TOTAL] += ms;
+    c->flushes_timed++;
+    c->events_pending = false;
+    return TRGL_OK;
+}
+
+int trgl_flush(trgl_ctx* c) {
+    CHKCTX(c);
+    if (c->draws.empty() && !c->clear_pending) return TRGL_OK;
+    int r;
+    if ((r = resolve_events(c))) return r;
+    const uint64_t N = c->queued_tris;
+    const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
+    hipStream_t s = c->stream;
+
+    FrameParams fp; std::memset(&fp, 0, sizeof(fp));
+    fp.fb = c->fb; fp.zb = c->zb; fp.W = c->W; fp.H = c->H; fp.bpp = c->bpp;
+    fp.tiles_x = c->tiles_x; fp.tiles_y = c->tiles_y;
+    fp.strip_y0 = c->strip_y0; fp.strip_y1 = c->strip_y1;
+    fp.strip_ty0 = c->strip_y0 / TRGL_TILE;
+    fp.strip_ty1 = (c->strip_y1 + TRGL_TILE - 1) / TRGL_TILE;
+    if (c->strip_y1 <= c->strip_y0) fp.strip_ty1 = fp.strip_ty0;
+    fp.init_from_clear = c->clear_pending ? 1 : 0;
+    fp.clear_color = c->clear_color; fp.clear_z = c->clear_z;
+    std::memcpy(fp.vp, c->vp, sizeof(fp.vp));
+
+    bool flat_only = true;
+    for (auto& d : c->draws) if (d.kind != TRGL_SHADER_FLAT) flat_only = false;
+
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
+    uint32_t P = 0;
+    if (N) {
+        // grow per-triangle buffers together
+        if (N > c->cap_tris) {
+            size_t ncap = N + N / 4 + 1024;
+            if ((r = realloc_dev(c, (void**)&c->recs, ncap * sizeof(TriRec)))) return r;
+            if ((r = realloc_dev(c, (void**)&c->cnt, ncap * 4))) return r;
+            if ((r = realloc_dev(c, (void**)&c->off, ncap * 4))) return r;
+            if ((r = realloc_dev(c, (void**)&c->tilebox, ncap * sizeof(uint2)))) return r;
+            c->cap_tris = ncap;
+        }
+        if ((r = grow(c, c->scan_tmp, c->cap_scan, (size_t)scan_num_blocks(N) + 16))) return r;
+        std::memcpy(c->draws_pinned, c->draws.data(), c->draws.size() * sizeof(DrawDesc));
+        HIPCHK(c, hipMemcpyAsync(c->draws_dev, c->draws_pinned, c->draws.size() * sizeof(DrawDesc), hipMemcpyHostToDevice, s));
+        for (size_t i = 0; i < c->draws.size(); ++i)
+            launch_setup(s, fp, c->draws_dev, (int)i, c->draws[i].n, c->recs, c->cnt, c->tilebox, c->stats_dev);
+        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
+        launch_exclusive_scan(s, c->cnt, c->off, N, c->scan_tmp, &c->stats_dev->pairs_total);
+        HIPCHK(c, hipMemcpyAsync(&c->stats_pinned->pairs_total, &c->stats_dev->pairs_total, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        unsigned long long P64 = c->stats_pinned->pairs_total;
+        if (P64 > 0xfffffff0ull) return fail(c, TRGL_E_UNSUPPORTED, "flush: more than 2^32 triangle-tile pairs; submit in smaller batches");
+        P = (uint32_t)P64;
+    } else if (c->profiling) {
+        HIPCHK(c, hipEventRecord(c->ev[1], s));
+    }
+    HIPCHK(c, hipMemsetAsync(c->tile_start, 0, ntiles * 4, s));
+    HIPCHK(c, hipMemsetAsync(c->tile_end, 0, ntiles * 4, s));
+    int cur = 0;
+    if (P) {
+        if (P > c->cap_pairs) {
+            size_t ncap = (size_t)P + P / 4 + 1024;
+            for (int k = 0; k < 2; ++k) {
+                if ((r = realloc_dev(c, (void**)&c->keys[k], ncap * 4))) return r;
+                if ((r = realloc_dev(c, (void**)&c->vals[k], ncap * 4))) return r;
+            }
+            c->cap_pairs = ncap;
+        }
+        launch_expand(s, (uint32_t)N, c->tiles_x, c->cnt, c->off, c->tilebox, c->keys[0], c->vals[0]);
+        int key_bits = 1; while ((size_t(1) << key_bits) < ntiles) ++key_bits;
+        int passes = (key_bits + 7) / 8;
+        int bits_per = (key_bits + passes - 1) / passes;
+        size_t hist_need = ((size_t)radix_num_workers(P) << bits_per) + 16;
+        if ((r = grow(c, c->hist, c->cap_hist, hist_need))) return r;
+        if ((r = grow(c, c->scan_tmp, c->cap_scan, (size_t)scan_num_blocks(hist_need) + 16))) return r;
+        for (int ps = 0; ps < passes; ++ps) {
+            launch_radix_pass(s, c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1], P, ps * bits_per, bits_per,
+                              c->hist, c->scan_tmp);
+            cur ^= 1;
+        }
+        launch_bounds(s, c->keys[cur], P, c->tile_start, c->tile_end);
+    }
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], s));
+    launch_raster(s, fp, flat_only, c->recs, c->vals[cur], c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev);
+    if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[3], s)); c->events_pending = true; }
+    HIPCHK(c, hipGetLastError());
+
+    c->triangles_total += N;
+    c->last_tris = N; c->last_pairs = P;
+    c->clear_pending = false;
+    bool had_stage = false;
+    for (auto& ch : c->stage) if (ch.used) had_stage = true;
+    c->draws.clear();
+    c->queued_tris = 0;
+    if (had_stage) {                       // staged host data may be recycled only once the kernels are done
+        HIPCHK(c, hipStreamSynchronize(s));
+        for (auto& ch : c->stage) ch.used = 0;
+    }
+    return TRGL_OK;
+}
+
+int trgl_sync(trgl_ctx* c) {
+    CHKCTX(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TRGL_OK;
+}
+
+static int flush_sync(trgl_ctx* c) {
+    int r = trgl_flush(c); if (r) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TRGL_OK;
+}
+
+int trgl_read_framebuffer(trgl_ctx* c, uint8_t* dst) {
+    CHKCTX(c);
+    if (!dst) return fail(c, TRGL_E_INVALID, "null destination");
+    int r = flush_sync(c); if (r) return r;
+    HIPCHK(c, hipMemcpy(dst, c->fb, (size_t)c->W * c->H * c->bpp, hipMemcpyDeviceToHost));
+    return TRGL_OK;
+}
+int trgl_write_framebuffer(trgl_ctx* c, const uint8_t* src) {
+    CHKCTX(c);
+    if (!src) return fail(c, TRGL_E_INVALID, "null source");
+    int r = flush_sync(c); if (r) return r;
+    HIPCHK(c, hipMemcpy(c->fb, src, (size_t)c->W * c->H * c->bpp, hipMemcpyHostToDevice));
+    return TRGL_OK;
+}
+int trgl_read_zbuffer(trgl_ctx* c, double* dst) {
+    CHKCTX(c);
+    if (!dst) return fail(c, TRGL_E_INVALID, "null destination");
+    int r = flush_sync(c); if (r) return r;
+    HIPCHK(c, hipMemcpy(dst, c->zb, (size_t)c->W * c->H * sizeof(double), hipMemcpyDeviceToHost));
+    return TRGL_OK;
+}
+int trgl_write_zbuffer(trgl_ctx* c, const double* src) {
+    CHKCTX(c);
+    if (!src) return fail(c, TRGL_E_INVALID, "null source");
+    int r = flush_sync(c); if (r) return r;
+    HIPCHK(c, hipMemcpy(c->zb, src, (size_t)c->W * c->H * sizeof(double), hipMemcpyHostToDevice));
+    return TRGL_OK;
+}
+
+int trgl_get_stats(trgl_ctx* c, trgl_stats* out) {
+    CHKCTX(c);
+    if (!out) return fail(c, TRGL_E_INVALID, "null stats");
+    int r = flush_sync(c); if (r) return r;
+    HIPCHK(c, hipMemcpy(c->stats_pinned, c->stats_dev, sizeof(DevStats), hipMemcpyDeviceToHost));
+    const DevStats& s = *c->stats_pinned;
+    out->triangles_rasterized = c->triangles_total;
+    out->fragments_drawn = s.fragments;
+    out->min_x = s.min_x; out->min_y = s.min_y; out->max_x = s.max_x; out->max_y = s.max_y;
+    out->min_z = zkey_decode(s.zmin_key); out->max_z = zkey_decode(s.zmax_key);
+    return TRGL_OK;
+}
+
+int trgl_reset_stats(trgl_ctx* c) {
+    CHKCTX(c);
+    int r = flush_sync(c); if (r) return r;
+    c->triangles_total = 0;
+    return reset_dev_stats(c);
+}
+
+int trgl_format_stats(const trgl_stats* s, char* buf, size_t buflen) {   // our_gl.cpp:205-209
+    if (!s || !buf) return TRGL_E_INVALID;
+    char lo[64], hi[64];
+    if (std::isfinite(s->min_z)) std::snprintf(lo, sizeof lo, "%f", s->min_z); else std::snprintf(lo, sizeof lo, "inf");
+    if (std::isfinite(s->max_z)) std::snprintf(hi, sizeof hi, "%f", s->max_z); else std::snprintf(hi, sizeof hi, "-inf");
+    int n = std::snprintf(buf, buflen, "DEBUG: triangles=%llu fragments_drawn=%llu bbox=[%d,%d] - [%d,%d] z-range=[%s,%s]\n",
+                          (unsigned long long)s->triangles_rasterized, (unsigned long long)s->fragments_drawn,
+                          s->min_x, s->min_y, s->max_x, s->max_y, lo, hi);
+    return (n < 0 || (size_t)n >= buflen) ? TRGL_E_INVALID : TRGL_OK;
+}
+
+void* trgl_framebuffer_device_ptr(trgl_ctx* c) { return c ? c->fb : nullptr; }
+void* trgl_zbuffer_device_ptr(trgl_ctx* c) { return c ? c->zb : nullptr; }
+void* trgl_stream(trgl_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int trgl_set_profiling(trgl_ctx* c, int on) {
+    CHKCTX(c);
+    int r = resolve_events(c); if (r) return r;
+    c->profiling = on != 0;
+    return TRGL_OK;
+}
+int trgl_get_phase_ms(trgl_ctx* c, double ms[TRGL_NUM_PHASES], uint64_t* flushes) {
+    CHKCTX(c);
+    int r = resolve_events(c); if (r) return r;
+    if (ms) for (int i = 0; i < TRGL_NUM_PHASES; ++i) ms[i] = c->phase_ms[i];
+    if (flushes) *flushes = c->flushes_timed;
+    return TRGL_OK;
+}
+int trgl_reset_phase_ms(trgl_ctx* c) {
+    CHKCTX(c);
+    int r = resolve_events(c); if (r) return r;
+    for (int i = 0; i < TRGL_NUM_PHASES; ++i) c->phase_ms[i] = 0;
+    c->flushes_timed = 0;
+    return TRGL_OK;
+}
+int trgl_get_last_flush_info(trgl_ctx* c, uint64_t* triangles, uint64_t* pairs, uint64_t* tiles) {
+    if (!c) return TRGL_E_INVALID;
+    if (triangles) *triangles = c->last_tris;
+    if (pairs) *pairs = c->last_pairs;
+    if (tiles) *tiles = (uint64_t)c->tiles_x * c->tiles_y;
+    return TRGL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// trgl_device.h — structs shared by the host side (trgl_api.cpp) and the gfx950 kernels.
+//
+// Data layout in HBM (one context):
+//   fb      uint8  [H][W][bpp]      TGAImage layout, row y=0 first (tgaimage.cpp:32-39)
+//   zb      double [H][W]           the reference's global zbuffer (our_gl.cpp:15,72-74)
+//   recs    TriRec [N]              one 128-B line per submitted triangle, written by setup
+//   cnt/off uint32 [N]              tiles overlapped per triangle and its exclusive scan
+//   keys/vals uint32 [P] x2         (tile id, triangle id) pairs, ping-pong for the radix passes
+//   tile_start/tile_end uint32[T]   per-tile slice of the sorted pair list
+#pragma once
+#include <stdint.h>
+#include "../../include/trgl.h"
+
+#define TRGL_TILE      32          // tile is TILE x TILE pixels, owned by ONE wavefront
+#define TRGL_TILE_LOG2 5
+#define TRGL_TILE_PIX  (TRGL_TILE * TRGL_TILE)
+#define TRGL_WAVES_PER_BLOCK 4     // a raster workgroup covers 4 horizontally adjacent tiles
+#define TRGL_MAX_DRAWS 64          // draws per flush (each with its own shader kind + uniforms)
+
+// Per-triangle setup record: everything the pixel loop needs, hoisted exactly as SURVEY §8(a) A4/A6
+// allows (same operations on the same operands as our_gl.cpp:77-86,168-170, so bit-identical).
+struct alignas(128) TriRec {
+    double ax, ay;            // screen[0]                       (our_gl.cpp:117-121)
+    double s0x, s0y;          // C.x - A.x, B.x - A.x            (our_gl.cpp:78)
+    double s1x, s1y;          // C.y - A.y, B.y - A.y            (our_gl.cpp:79)
+    double uz;                // s0x*s1y - s0y*s1x = cross().z   (our_gl.cpp:80, geometry.h:147)
+    double z0, z1, z2;        // NDC z of the three vertices     (our_gl.cpp:156-158)
+    double iw0, iw1, iw2;     // |w|>1e-12 ? 1/w : 0             (our_gl.cpp:168-170)
+    uint16_t bx0, by0, bx1, by1;   // clamped pixel bbox, inclusive (our_gl.cpp:130-133)
+    uint32_t color;           // FLAT / GOURAUD packed BGRA
+    uint32_t draw;            // index into the flush's draw table
+    uint32_t local;           // triangle index inside its draw (varyings = draw.vary + local*K)
+};
+static_assert(sizeof(TriRec) == 128, "TriRec must be one 128-B line");
+
+struct DevTexture {
+    const uint8_t* data;
+    int32_t w, h, bpp, pad;
+};
+
+struct DrawDesc {             // one trgl_draw() call, resident on the device for the flush
+    const double*   clip;     // [n][12]
+    const double*   vary;     // [n][K] or null
+    const uint32_t* colors;   // [n] or null
+    uint32_t        n;
+    uint32_t        first;    // global index of this draw's first triangle within the flush
+    int32_t         kind;
+    int32_t         K;
+    trgl_uniforms   u;
+};
+
+// Device-side mirror of the reference's counters (our_gl.cpp:18-22).  z range is kept as
+// order-preserving uint64 keys so atomicMin/atomicMax work on it.
+struct DevStats {
+    unsigned long long fragments;
+    unsigned long long zmin_key, zmax_key;
+    int32_t min_x, min_y, max_x, max_y;
+    unsigned long long pairs_total;      // written by the scan spine (implementation traffic)
+};
+
+struct FrameParams {
+    uint8_t* fb;
+    double*  zb;
+    int32_t  W, H, bpp;
+    int32_t  tiles_x, tiles_y;
+    int32_t  strip_y0, strip_y1;      // rows this context owns
+    int32_t  strip_ty0, strip_ty1;    // tile rows intersecting the strip: [ty0, ty1)
+    int32_t  init_from_clear;         // 1: tiles start from the clear values, not from HBM
+    uint32_t clear_color;             // packed BGRA
+    double   clear_z;
+    double   vp[8];                   // rows 0 and 1 of the Viewport matrix (our_gl.cpp:117-121)
+};
