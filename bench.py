@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py — whole-job throughput of the rasterize() hot path on MI355X.
+
+Workload (BASELINE.json configs[3], the one its metric "triangles/sec ... at 4096x4096" is quoted on):
+10 M synthetic random triangles, 4096x4096 RGB framebuffer + fp64 z-buffer, flat shader.
+A "step" is one full frame: clear -> setup -> stable tile binning -> LDS tile raster -> tile flush, with the
+triangle stream already resident in HBM when the timed region starts.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): strong scaling on the SAME frame — rank r owns
+framebuffer rows [r*H/N, (r+1)*H/N), every rank streams all triangles through setup (replicating 96 B/triangle of
+reads is cheaper than moving records over xGMI) and the colour strips are joined with one RCCL all-gather.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+class _DevBuf:
+    """Expose a raw device pointer to torch through __cuda_array_interface__."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def cpu_baseline(clip, col, W, H, sample):
+    """Single-thread CPU rate on a bounded prefix of the same workload: the reference's own rasterize()
+    (oracle/_ref, built -O3 -DNDEBUG -ffp-contract=off) when it travelled to this box, else the C restatement."""
+    from oracle import orc
+    n = min(sample, clip.shape[0])
+    desc = f"first {n} triangles of the same 4096x4096 scene, rasterize() loop only"
+    if os.path.exists(orc.REF_HARNESS_FAST):
+        from tinyrenderder_amd import scenes
+        _, _, _, secs = orc.run_reference(W, H, 3, scenes.init_viewport(0, 0, W, H), [(orc.FLAT, None, clip[:n], None, col[:n])],
+                                          harness=orc.REF_HARNESS_FAST, with_time=True)
+        kind = "reference"
+    else:
+        o = orc.Oracle(W, H, 3)
+        t0 = time.perf_counter()
+        o.draw(orc.FLAT, clip[:n], colors=col[:n])
+        secs = time.perf_counter() - t0
+        kind = "port"
+    return {"value": n / secs, "unit": "triangles/s", "cores": 1, "kind": kind, "sample": desc,
+            "seconds": round(secs, 3), "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--triangles", type=int, default=10_000_000)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="triangles timed on the host CPU (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    from tinyrenderder_amd import scenes
+    from tinyrenderder_amd.api import Context, FLAT, PHASE_RASTER, PHASE_SETUP, PHASE_BIN, PHASE_TOTAL
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W = H = args.size
+    N = args.triangles
+    clip, col = scenes.random_triangles(N, W, H)                    # same seed on every rank
+    dclip = torch.from_numpy(clip).cuda()
+    dcol = torch.from_numpy(col.view(np.int32)).cuda()
+
+    ctx = Context(W, H, 3, device=local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)          # order with torch / RCCL on one stream
+    rows = H // world
+    y0, y1 = rank * rows, (rank + 1) * rows if rank < world - 1 else H
+    full_fb = None
+    if world > 1:
+        assert H % world == 0, "equal strips needed for the in-place all-gather"
+        ctx.set_strip(y0, y1)
+        full_fb = torch.as_tensor(_DevBuf(ctx.framebuffer_ptr, W * H * 3), device="cuda")
+
+    def step():
+        ctx.clear()
+        ctx.draw(FLAT, dclip, colors=dcol, device=True)
+        ctx.flush()
+        if world > 1:   # join the colour strips: every rank ends with the whole TGAImage buffer
+            dist.all_gather_into_tensor(full_fb, full_fb[y0 * W * 3: y1 * W * 3])
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.set_profiling(True)
+    ctx.reset_phase_ms()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    phase_ms, nfl = ctx.phase_ms()
+    info = ctx.last_flush_info()
+    ctx.set_profiling(False)
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        tri_per_s = N * args.steps / elapsed
+        # dominant kernel = the tile raster; algorithmic bytes per launch: every pixel's colour and z
+        # leave the chip once (W*H*11 B) and every triangle's clip-space vertices are consumed once (N*96 B).
+        algo_bytes = (W * H * 11 + N * 96) / world if world > 1 else (W * H * 11 + N * 96)
+        raster_ms = phase_ms[PHASE_RASTER] / max(nfl, 1)
+        achieved = algo_bytes / (raster_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if world == 1 and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("workload") == f"c4_{W}x{H}_{N}":
+                traffic = tj.get("raster_hbm_bytes_per_launch")
+        out = {
+            "metric": "triangles/sec (+ Mpixels/sec) at 4096x4096; achieved HBM GB/s vs peak",
+            "value": tri_per_s, "unit": "triangles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"configs[3]: {N} synthetic random triangles, {W}x{H} RGB + fp64 z, flat shader",
+                       "width": W, "height": H, "triangles": N, "tile": 32,
+                       "parallelism": f"screen strips x{world}" + (" + RCCL all-gather of colour strips" if world > 1 else "")},
+            "mpixels_per_s": W * H * args.steps / elapsed / 1e6,
+            "tri_tile_pairs": info["pairs"],
+            "phase_ms": {"setup": phase_ms[PHASE_SETUP] / max(nfl, 1), "bin": phase_ms[PHASE_BIN] / max(nfl, 1),
+                         "raster": raster_ms, "flush_total": phase_ms[PHASE_TOTAL] / max(nfl, 1)},
+            "roofline": {"bound": "hbm", "kernel": "k_raster<flat>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": raster_ms},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(clip, col, W, H, args.cpu_sample)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

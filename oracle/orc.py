@@ -17,6 +17,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtrgl_oracle.so")
 REF_HARNESS = os.path.join(HERE, "_ref", "ref_harness")
+REF_HARNESS_FAST = os.path.join(HERE, "_ref", "ref_harness_fast")   # -O3 -DNDEBUG build, for cpu_baseline timing
 
 MAX_TEXTURES = 16
 FLAT, GOURAUD, PHONG, EYE = 0, 1, 2, 3
@@ -36,8 +37,10 @@ class Stats(C.Structure):
                 ("min_z", C.c_double), ("max_z", C.c_double)]
 
     def astuple(self):
+        # z range as (value, sign bit) so that -0.0 and +0.0 compare unequal, as their printed forms do
+        import math
         return (self.triangles_rasterized, self.fragments_drawn, self.min_x, self.min_y, self.max_x, self.max_y,
-                self.min_z, self.max_z)
+                self.min_z, self.max_z, math.copysign(1.0, self.min_z), math.copysign(1.0, self.max_z))
 
 
 class Texture(C.Structure):
@@ -179,12 +182,14 @@ def parse_stats_line(line: str):
     return tri, frag, x0, y0, x1, y1, m.group(7), m.group(8)
 
 
-def run_reference(width, height, bpp, viewport, draws, textures=None, clear_bgra=(0, 0, 0, 255), z_clear=np.inf):
-    """Render with the reference's own rasterize(); returns (fb[h,w,bpp] u8, z[h,w] f64, stats line)."""
+def run_reference(width, height, bpp, viewport, draws, textures=None, clear_bgra=(0, 0, 0, 255), z_clear=np.inf,
+                  harness=None, with_time=False):
+    """Render with the reference's own rasterize(); returns (fb[h,w,bpp] u8, z[h,w] f64, stats line)
+    [+ seconds spent in the rasterize() loops when with_time]."""
     with tempfile.TemporaryDirectory() as d:
         sp, op = os.path.join(d, "scene.bin"), os.path.join(d, "out.bin")
         write_scene(sp, width, height, bpp, viewport, draws, textures, clear_bgra, z_clear)
-        subprocess.run([REF_HARNESS, "scene", sp, op], check=True)
+        subprocess.run([harness or REF_HARNESS, "scene", sp, op], check=True)
         raw = open(op, "rb").read()
     nfb = width * height * bpp
     fb = np.frombuffer(raw, np.uint8, nfb).reshape(height, width, bpp).copy()
@@ -193,12 +198,16 @@ def run_reference(width, height, bpp, viewport, draws, textures=None, clear_bgra
     off += width * height * 8
     (ln,) = struct.unpack_from("<i", raw, off)
     line = raw[off + 4: off + 4 + ln].decode()
+    if with_time:
+        toff = off + ((4 + ln + 7) & ~7)
+        (secs,) = struct.unpack_from("<d", raw, toff)
+        return fb, z, line.strip(), secs
     return fb, z, line.strip()
 
 
 def format_stats_line(stats_tuple) -> str:
     """The print_render_stats() line (our_gl.cpp:205-209) for an oracle/GPU stats tuple."""
-    tri, frag, x0, y0, x1, y1, zlo, zhi = stats_tuple
+    tri, frag, x0, y0, x1, y1, zlo, zhi = stats_tuple[:8]
     lo = f"{zlo:.6f}" if np.isfinite(zlo) else "inf"
     hi = f"{zhi:.6f}" if np.isfinite(zhi) else "-inf"
     return f"DEBUG: triangles={tri} fragments_drawn={frag} bbox=[{x0},{y0}] - [{x1},{y1}] z-range=[{lo},{hi}]"

@@ -21,6 +21,7 @@
 #include "our_gl.h"          // from -I/root/reference
 #include "trgl_oracle.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -95,6 +96,7 @@ int run_scene(const char* in_path, const char* out_path) {
     if (!(zclear == std::numeric_limits<double>::infinity()))
         for (auto& z : zbuffer) z = zclear;
 
+    double raster_seconds = 0.0;      // time inside the per-triangle rasterize() loops only
     for (int d = 0; d < ndraws; ++d) {
         int kind = r.get<int32_t>(); r.get<int32_t>();
         uint64_t n = r.get<uint64_t>();
@@ -107,6 +109,7 @@ int run_scene(const char* in_path, const char* out_path) {
 
         FlatShader flat; GouraudShader gour; RestatedFragShader rest;
         rest.kind = kind; rest.u = &u; rest.tex = tex.data();
+        auto t0 = std::chrono::steady_clock::now();
         for (uint64_t i = 0; i < n; ++i) {
             vec4 tri[3];
             for (int v = 0; v < 3; ++v) for (int c = 0; c < 4; ++c) tri[v][c] = clip[i * 12 + v * 4 + c];
@@ -122,6 +125,7 @@ int run_scene(const char* in_path, const char* out_path) {
                 rasterize(tri, rest, framebuffer);
             }
         }
+        raster_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
 
     std::ostringstream captured;
@@ -139,6 +143,8 @@ int run_scene(const char* in_path, const char* out_path) {
     int32_t len = (int32_t)line.size();
     out.write((const char*)&len, 4);
     out.write(line.data(), len);
+    out.write(pad, (8 - (4 + len) % 8) % 8);
+    out.write((const char*)&raster_seconds, 8);
     return out ? 0 : 3;
 }
 

@@ -24,7 +24,7 @@ SYMBOLS = [
     "trgl_create", "trgl_destroy", "trgl_last_error", "trgl_set_viewport", "trgl_init_viewport", "trgl_clear",
     "trgl_upload_texture", "trgl_set_strip", "trgl_draw", "trgl_flush", "trgl_sync", "trgl_read_framebuffer",
     "trgl_write_framebuffer", "trgl_read_zbuffer", "trgl_write_zbuffer", "trgl_get_stats", "trgl_reset_stats",
-    "trgl_format_stats", "trgl_framebuffer_device_ptr", "trgl_zbuffer_device_ptr", "trgl_stream",
+    "trgl_format_stats", "trgl_framebuffer_device_ptr", "trgl_zbuffer_device_ptr", "trgl_stream", "trgl_set_stream",
     "trgl_set_profiling", "trgl_get_phase_ms", "trgl_reset_phase_ms", "trgl_get_last_flush_info",
 ]
 
@@ -44,8 +44,10 @@ class Stats(C.Structure):
                 ("min_z", C.c_double), ("max_z", C.c_double)]
 
     def astuple(self):
+        # z range as (value, sign bit) so that -0.0 and +0.0 compare unequal, as their printed forms do
+        import math
         return (self.triangles_rasterized, self.fragments_drawn, self.min_x, self.min_y, self.max_x, self.max_y,
-                self.min_z, self.max_z)
+                self.min_z, self.max_z, math.copysign(1.0, self.min_z), math.copysign(1.0, self.max_z))
 
 
 def make_uniforms(model_view=None, key=(0, 0, 1), fill=(0, 0, 1), rim=(0, 0, 1), normal_map_strength=1.0,
@@ -98,6 +100,7 @@ def load_library(path: str = LIB_PATH):
     L.trgl_format_stats.argtypes = [C.POINTER(Stats), C.c_char_p, C.c_size_t]
     for name in ("trgl_framebuffer_device_ptr", "trgl_zbuffer_device_ptr", "trgl_stream"):
         getattr(L, name).argtypes = [vp]; getattr(L, name).restype = C.c_void_p
+    L.trgl_set_stream.argtypes = [vp, C.c_void_p]
     L.trgl_set_profiling.argtypes = [vp, C.c_int]
     L.trgl_get_phase_ms.argtypes = [vp, dp, u64p]
     L.trgl_reset_phase_ms.argtypes = [vp]
@@ -253,6 +256,10 @@ class Context:
     @property
     def stream(self) -> int:
         return self.L.trgl_stream(self.h)
+
+    def set_stream(self, hip_stream):
+        """Enqueue on the caller's hipStream_t (int pointer, e.g. torch.cuda.current_stream().cuda_stream)."""
+        self._chk(self.L.trgl_set_stream(self.h, hip_stream))
 
     # ---- measurement ----
     def set_profiling(self, on: bool):

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
 
     uint32_t frags = 0;
     double zmin = __builtin_inf(), zmax = -__builtin_inf();
+    const bool zero_locked = stats->zero_locked != 0;
 
     // ---- the tile's triangles, in submission order --------------------------------------------
     for (uint32_t p = beg; p < end; ++p) {
@@ -281,6 +282,10 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                     ct[li] = color;                                               // :192
                     ++frags;                                                      // :194
                     zmin = dmin(zmin, z); zmax = dmax(zmax, z);                   // :197-198
+                    if (z == 0.0 && !zero_locked) {       // rare: remember which signed zero came first
+                        unsigned long long order = ((unsigned long long)tri << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
+                        atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
+                    }
                 }
             }
         }
@@ -346,6 +351,16 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
     }
 }
 
+// after the raster kernel of a flush: fix the sign of a zero z-range end (see DevStats)
+__global__ void k_fold_stats(DevStats* __restrict__ s) {
+    if (!s->zero_locked && (s->zero_pos_key != TRGL_ZERO_KEY_EMPTY || s->zero_neg_key != TRGL_ZERO_KEY_EMPTY)) {
+        s->zero_sign = s->zero_neg_key < s->zero_pos_key ? 1u : 0u;
+        s->zero_locked = 1u;
+    }
+    s->zero_pos_key = TRGL_ZERO_KEY_EMPTY;
+    s->zero_neg_key = TRGL_ZERO_KEY_EMPTY;
+}
+
 }  // namespace
 
 namespace trgl {
@@ -360,6 +375,7 @@ void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const T
         hipLaunchKernelGGL(k_raster<true>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats);
     else
         hipLaunchKernelGGL(k_raster<false>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats);
+    hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(1), 0, s, stats);
 }
 
 }  // namespace trgl

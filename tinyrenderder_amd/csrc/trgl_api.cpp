@@ -26,7 +26,8 @@ struct StageChunk { char* base; size_t cap, used; };
 struct trgl_ctx {
     int device = 0;
     int W = 0, H = 0, bpp = 0, tiles_x = 0, tiles_y = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // the stream in use
+    hipStream_t own_stream = nullptr;   // created with the context
     uint8_t* fb = nullptr;
     double* zb = nullptr;
     double vp[16];
@@ -94,6 +95,8 @@ static int reset_dev_stats(trgl_ctx* c) {
     s.zmax_key = zkey_host(-std::numeric_limits<double>::infinity());
     s.min_x = INT32_MAX; s.min_y = INT32_MAX; s.max_x = INT32_MIN; s.max_y = INT32_MIN;
     s.pairs_total = 0;
+    s.zero_pos_key = s.zero_neg_key = TRGL_ZERO_KEY_EMPTY;
+    s.zero_locked = 0; s.zero_sign = 0;
     *c->stats_pinned = s;
     HIPCHK(c, hipMemcpyAsync(c->stats_dev, c->stats_pinned, sizeof(DevStats), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -133,7 +136,8 @@ int trgl_create(int device, int width, int height, int bpp, trgl_ctx** out) {
     std::memset(c->tex_host, 0, sizeof(c->tex_host));
     size_t npx = (size_t)width * height, ntiles = (size_t)c->tiles_x * c->tiles_y;
 #define CRE(expr) do { hipError_t e2 = (expr); if (e2 != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e2); trgl_destroy(c); return TRGL_E_HIP; } } while (0)
-    CRE(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CRE(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
     CRE(hipMalloc((void**)&c->fb, npx * bpp));
     CRE(hipMalloc((void**)&c->zb, npx * sizeof(double)));
     CRE(hipMalloc((void**)&c->tex_dev, sizeof(c->tex_host)));
@@ -165,7 +169,7 @@ int trgl_destroy(trgl_ctx* c) {
     if (c->draws_pinned) (void)hipHostFree(c->draws_pinned);
     if (c->stats_pinned) (void)hipHostFree(c->stats_pinned);
     for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return TRGL_OK;
 }
@@ -439,6 +443,9 @@ int trgl_get_stats(trgl_ctx* c, trgl_stats* out) {
     out->fragments_drawn = s.fragments;
     out->min_x = s.min_x; out->min_y = s.min_y; out->max_x = s.max_x; out->max_y = s.max_y;
     out->min_z = zkey_decode(s.zmin_key); out->max_z = zkey_decode(s.zmax_key);
+    // +0.0 == -0.0: the reference keeps whichever zero it met first (std::min/max, our_gl.cpp:197-198)
+    if (out->min_z == 0.0 && s.zero_locked) out->min_z = s.zero_sign ? -0.0 : 0.0;
+    if (out->max_z == 0.0 && s.zero_locked) out->max_z = s.zero_sign ? -0.0 : 0.0;
     return TRGL_OK;
 }
 
@@ -463,6 +470,15 @@ int trgl_format_stats(const trgl_stats* s, char* buf, size_t buflen) {   // our_
 void* trgl_framebuffer_device_ptr(trgl_ctx* c) { return c ? c->fb : nullptr; }
 void* trgl_zbuffer_device_ptr(trgl_ctx* c) { return c ? c->zb : nullptr; }
 void* trgl_stream(trgl_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int trgl_set_stream(trgl_ctx* c, void* hip_stream) {
+    CHKCTX(c);
+    int r = trgl_flush(c); if (r) return r;
+    if ((r = resolve_events(c))) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return TRGL_OK;
+}
 
 int trgl_set_profiling(trgl_ctx* c, int on) {
     CHKCTX(c);

@@ -56,7 +56,13 @@ struct DevStats {
     unsigned long long zmin_key, zmax_key;
     int32_t min_x, min_y, max_x, max_y;
     unsigned long long pairs_total;      // written by the scan spine (implementation traffic)
+    // std::min/std::max keep the FIRST of two equal values (our_gl.cpp:197-198), and +0.0 == -0.0:
+    // when the z range ends in a zero its sign is that of the first zero written, in the reference's
+    // order (triangle, x, y).  Keys = tri<<32 | x<<16 | y of the first +0 / -0 fragment of this flush.
+    unsigned long long zero_pos_key, zero_neg_key;
+    uint32_t zero_locked, zero_sign;     // set by k_fold_stats once any zero has been written
 };
+#define TRGL_ZERO_KEY_EMPTY 0xffffffffffffffffull
 
 struct FrameParams {
     uint8_t* fb;
