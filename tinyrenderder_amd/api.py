@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -75,6 +76,14 @@ def load_library(path: str = LIB_PATH):
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: torch wheels bundle their own libamdhip64.  If libtrgl.so pulled in
+    # /opt/rocm's copy first, a later `import torch` in the same process finds no GPUs; loaded after torch,
+    # libtrgl.so binds to the runtime that is already there.  (A C/C++ host without torch is unaffected.)
+    if "torch" not in sys.modules and not os.environ.get("TRGL_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(path):
         raise TrglError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback.")

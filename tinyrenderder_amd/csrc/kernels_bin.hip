@@ -39,27 +39,57 @@ __device__ __forceinline__ int wave_max_i(int v) {
 
 // ---------------------------------------------------------------------------------------------
 // setup: one thread per triangle of one draw.  Follows our_gl.cpp:89-141 line by line.
+// HBM traffic is staged through LDS so that both the 96-B/triangle clip stream and the 128-B/triangle
+// record stream move as 16 B per lane, fully coalesced (a lane reading its own 96-B triangle straight
+// from HBM touches 64 different lines per load instruction).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_setup(FrameParams fp, const DrawDesc* __restrict__ draws, int draw_idx,
-                                               TriRec* __restrict__ recs, uint32_t* __restrict__ cnt,
-                                               uint2* __restrict__ tilebox, DevStats* __restrict__ stats) {
+constexpr int SETUP_THREADS = 256;
+
+__global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const DrawDesc* __restrict__ draws, int draw_idx,
+                                                         TriRec* __restrict__ recs, uint32_t* __restrict__ cnt,
+                                                         uint2* __restrict__ tilebox, DevStats* __restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) double s_buf[SETUP_THREADS * 16];    // 32 KB: in [256][12], then out [256][16]
     const DrawDesc& d = draws[draw_idx];
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool in_range = i < d.n;
+    const uint32_t b0 = blockIdx.x * SETUP_THREADS;
+    const uint32_t nb = min((uint32_t)SETUP_THREADS, d.n - b0);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t i = b0 + tid;
+    const bool in_range = tid < nb;
+
+    // ---- clip stream in: nb*96 contiguous bytes ------------------------------------------------
+    const double* src = d.clip + (size_t)b0 * 12;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const double2* s2 = reinterpret_cast<const double2*>(src);
+        double2* l2 = reinterpret_cast<double2*>(s_buf);
+        for (uint32_t k = tid; k < nb * 6; k += SETUP_THREADS) l2[k] = s2[k];
+    } else {
+        for (uint32_t k = tid; k < nb * 12; k += SETUP_THREADS) s_buf[k] = src[k];
+    }
+    __syncthreads();
+    double v[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) v[k] = in_range ? s_buf[tid * 12 + k] : 0.0;
+    __syncthreads();
+
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;   // contribution to bbox stats
     uint32_t ntiles = 0;
     uint2 tb = make_uint2(0, 0);
-    if (in_range) {
-        const double* c = d.clip + (size_t)i * 12;
-        double v[12];
+    TriRec r;
+    {
+        uint4* z4 = reinterpret_cast<uint4*>(&r);
 #pragma unroll
-        for (int k = 0; k < 12; ++k) v[k] = c[k];
+        for (int k = 0; k < 8; ++k) z4[k] = make_uint4(0, 0, 0, 0);
+    }
+    if (in_range) {
         bool ok = !(v[3] <= 1e-12 || v[7] <= 1e-12 || v[11] <= 1e-12);                     // :94 (:97 is dead)
         double ndc[12];
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < 3; ++q) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ndc[4 * q + k] = v[4 * q + k] / v[4 * q + 3];      // :101
+            for (int k = 0; k < 3; ++k) ndc[4 * q + k] = v[4 * q + k] / v[4 * q + 3];      // :101
+            // w / w is exactly 1.0 for every finite non-zero w and NaN for an infinite one
+            ndc[4 * q + 3] = __builtin_isfinite(v[4 * q + 3]) ? 1.0 : __builtin_nan("");
+        }
         bool zo0 = (ndc[2] < -1.0 || ndc[2] > 1.0), zo1 = (ndc[6] < -1.0 || ndc[6] > 1.0),
              zo2 = (ndc[10] < -1.0 || ndc[10] > 1.0);
         ok = ok && !(zo0 && zo1 && zo2);                                                   // :103-106
@@ -78,7 +108,6 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const DrawDesc* _
         ok = ok && !(min_x_px > max_x_px || min_y_px > max_y_px);                          // :135
         if (ok) {
             bx0 = min_x_px; by0 = min_y_px; bx1 = max_x_px; by1 = max_y_px;                // :138-141
-            TriRec r;
             r.ax = sx[0]; r.ay = sy[0];
             r.s0x = sx[2] - sx[0]; r.s0y = sx[1] - sx[0];                                  // :78
             r.s1x = sy[2] - sy[0]; r.s1y = sy[1] - sy[0];                                  // :79
@@ -90,7 +119,6 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const DrawDesc* _
             r.bx0 = (uint16_t)bx0; r.by0 = (uint16_t)by0; r.bx1 = (uint16_t)bx1; r.by1 = (uint16_t)by1;
             r.color = d.colors ? d.colors[i] : 0xffffffffu;
             r.draw = (uint32_t)draw_idx; r.local = i;
-            recs[d.first + i] = r;
             // barycentric() rejects every pixel when |u.z| < 1e-12 (our_gl.cpp:82-83): no pairs then.
             // Rows outside this context's strip are not ours either.
             int y_lo = max(by0, fp.strip_y0), y_hi = min(by1, fp.strip_y1 - 1);
@@ -103,6 +131,20 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const DrawDesc* _
         }
         cnt[d.first + i] = ntiles;
         tilebox[d.first + i] = tb;
+    }
+    // ---- record stream out: nb*128 contiguous bytes, 16-B chunks XOR-swizzled in LDS so neither the
+    // per-thread writes (128-B stride) nor the linear read-out conflict on banks ------------------------
+    {
+        uint4* l4 = reinterpret_cast<uint4*>(s_buf);
+        const uint4* r4 = reinterpret_cast<const uint4*>(&r);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) l4[tid * 8 + (c ^ (tid & 7))] = r4[c];
+        __syncthreads();
+        uint4* dst = reinterpret_cast<uint4*>(recs + d.first + b0);
+        for (uint32_t k = tid; k < nb * 8; k += SETUP_THREADS) {
+            uint32_t t = k >> 3, c = k & 7;
+            dst[k] = l4[t * 8 + (c ^ (t & 7))];
+        }
     }
     // bbox stats (our_gl.cpp:138-141): one set of atomics per wave
     int wx0 = wave_min_i(bx0), wy0 = wave_min_i(by0), wx1 = wave_max_i(bx1), wy1 = wave_max_i(by1);

@@ -185,6 +185,20 @@ __device__ __forceinline__ int lds_index(int x, int y) {
     return ((y & (TRGL_TILE - 1)) << TRGL_TILE_LOG2) + ((x & (TRGL_TILE - 1)) ^ ((y & 3) << 3));
 }
 
+// A wave's batch of triangle records: lane i holds record i (8 x 16 B) and its triangle id.
+struct RecQ { uint4 q[8]; uint32_t tri; };
+__device__ __forceinline__ RecQ load_rec(const TriRec* __restrict__ recs, uint32_t tri, bool valid) {
+    RecQ r; r.tri = tri;
+    const uint4* p = reinterpret_cast<const uint4*>(recs + tri);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.q[k] = valid ? p[k] : make_uint4(0, 0, 0, 0);
+    return r;
+}
+__device__ __forceinline__ uint32_t bcast_u(uint32_t v, uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)j); }
+__device__ __forceinline__ double bcast_d(uint32_t lo, uint32_t hi, uint32_t j) {
+    return __hiloint2double(__builtin_amdgcn_readlane((int)hi, (int)j), __builtin_amdgcn_readlane((int)lo, (int)j));
+}
+
 template <bool FLAT_ONLY>
 __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
@@ -235,60 +249,86 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
     const bool zero_locked = stats->zero_locked != 0;
 
     // ---- the tile's triangles, in submission order --------------------------------------------
-    for (uint32_t p = beg; p < end; ++p) {
-        const uint32_t tri = __builtin_amdgcn_readfirstlane(vals[p]);
-        const TriRec& r = recs[tri];
-        const int x0 = max((int)r.bx0, px0), x1 = min((int)r.bx1, xa1);
-        const int y0 = max((int)r.by0, ya0), y1 = min((int)r.by1, ya1);
-        const double uz = r.uz;
-        for (int by = y0; by <= y1; by += 8) {
-            for (int bx = x0; bx <= x1; bx += 8) {
-                const int x = bx + (lane & 7), y = by + (lane >> 3);
-                const bool act = (x <= x1) && (y <= y1);
-                // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
-                const double pxc = (double)x + 0.5, pyc = (double)y + 0.5;        // :149
-                const double s0z = r.ax - pxc, s1z = r.ay - pyc;
-                const double ux = r.s0y * s1z - s0z * r.s1y;                      // geometry.h:145
-                const double uy = s0z * r.s1x - r.s0x * s1z;                      // geometry.h:146
-                const double b0 = 1.0 - (ux + uy) / uz;
-                const double b1 = uy / uz;
-                const double b2 = ux / uz;
-                bool cov = act && !(b0 < 0 || b1 < 0 || b2 < 0);                  // :152
-                const double z = b0 * r.z0 + b1 * r.z1 + b2 * r.z2;               // :156-158
-                cov = cov && __builtin_isfinite(z);                               // :160
-                if (__ballot(cov) == 0) continue;
-                const int li = lds_index(x, y);
-                const double zold = zt[li];
-                if (cov && (z < zold)) {                                          // :165
-                    uint32_t color;
-                    if (FLAT_ONLY) {
-                        color = r.color;
-                    } else {
-                        const DrawDesc& d = draws[r.draw];
-                        if (d.kind == TRGL_SHADER_FLAT) {
-                            color = r.color;
+    // 64 records at a time: lane i holds the 128-B record of the batch's i-th triangle in registers
+    // (the next batch is already in flight while this one is rasterized), and the per-triangle
+    // constants are broadcast with v_readlane into SGPRs.  One HBM round trip per 64 triangles
+    // instead of two dependent ones per triangle.
+    RecQ cur;
+    {
+        uint32_t p = beg + lane;
+        cur = load_rec(recs, vals[p < end ? p : (end > beg ? end - 1 : 0)], beg < end);
+    }
+    for (uint32_t bs = beg; bs < end; bs += 64) {
+        const uint32_t nbatch = min(64u, end - bs);
+        RecQ nxt = cur;
+        if (bs + 64 < end) {
+            uint32_t p = bs + 64 + lane;
+            nxt = load_rec(recs, vals[p < end ? p : end - 1], true);
+        }
+        for (uint32_t j = 0; j < nbatch; ++j) {
+            const double r_ax = bcast_d(cur.q[0].x, cur.q[0].y, j), r_ay = bcast_d(cur.q[0].z, cur.q[0].w, j);
+            const double r_s0x = bcast_d(cur.q[1].x, cur.q[1].y, j), r_s0y = bcast_d(cur.q[1].z, cur.q[1].w, j);
+            const double r_s1x = bcast_d(cur.q[2].x, cur.q[2].y, j), r_s1y = bcast_d(cur.q[2].z, cur.q[2].w, j);
+            const double uz = bcast_d(cur.q[3].x, cur.q[3].y, j);
+            const double r_z0 = bcast_d(cur.q[3].z, cur.q[3].w, j), r_z1 = bcast_d(cur.q[4].x, cur.q[4].y, j),
+                         r_z2 = bcast_d(cur.q[4].z, cur.q[4].w, j);
+            const uint32_t bb0 = bcast_u(cur.q[6].z, j), bb1 = bcast_u(cur.q[6].w, j);
+            const uint32_t r_color = bcast_u(cur.q[7].x, j);
+            const uint32_t tri = bcast_u(cur.tri, j);
+            const int x0 = max((int)(bb0 & 0xffff), px0), x1 = min((int)(bb1 & 0xffff), xa1);
+            const int y0 = max((int)(bb0 >> 16), ya0), y1 = min((int)(bb1 >> 16), ya1);
+            for (int by = y0; by <= y1; by += 8) {
+                for (int bx = x0; bx <= x1; bx += 8) {
+                    const int x = bx + (lane & 7), y = by + (lane >> 3);
+                    const bool act = (x <= x1) && (y <= y1);
+                    // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
+                    const double pxc = (double)x + 0.5, pyc = (double)y + 0.5;        // :149
+                    const double s0z = r_ax - pxc, s1z = r_ay - pyc;
+                    const double ux = r_s0y * s1z - s0z * r_s1y;                      // geometry.h:145
+                    const double uy = s0z * r_s1x - r_s0x * s1z;                      // geometry.h:146
+                    const double b0 = 1.0 - (ux + uy) / uz;
+                    const double b1 = uy / uz;
+                    const double b2 = ux / uz;
+                    bool cov = act && !(b0 < 0 || b1 < 0 || b2 < 0);                  // :152
+                    const double z = b0 * r_z0 + b1 * r_z1 + b2 * r_z2;               // :156-158
+                    cov = cov && __builtin_isfinite(z);                               // :160
+                    if (__ballot(cov) == 0) continue;
+                    const int li = lds_index(x, y);
+                    const double zold = zt[li];
+                    if (cov && (z < zold)) {                                          // :165
+                        uint32_t color;
+                        if (FLAT_ONLY) {
+                            color = r_color;
                         } else {
-                            double bc[3] = { b0, b1, b2 }, pc[3];
-                            const double denom = b0 * r.iw0 + b1 * r.iw1 + b2 * r.iw2;   // :172-174
-                            if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }
-                            else { pc[0] = (bc[0] * r.iw0) / denom; pc[1] = (bc[1] * r.iw1) / denom; pc[2] = (bc[2] * r.iw2) / denom; }
-                            const double* vary = d.vary + (size_t)r.local * d.K;
-                            if (d.kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(r.color, vary, pc);
-                            else if (d.kind == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
-                            else color = frag_eye(d.u, tex, vary, pc).bgra;
+                            const DrawDesc& d = draws[bcast_u(cur.q[7].y, j)];
+                            if (d.kind == TRGL_SHADER_FLAT) {
+                                color = r_color;
+                            } else {
+                                const double iw0 = bcast_d(cur.q[5].x, cur.q[5].y, j), iw1 = bcast_d(cur.q[5].z, cur.q[5].w, j),
+                                             iw2 = bcast_d(cur.q[6].x, cur.q[6].y, j);
+                                double pc[3];
+                                const double denom = b0 * iw0 + b1 * iw1 + b2 * iw2;              // :172-174
+                                if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }  // :177-185
+                                else { pc[0] = (b0 * iw0) / denom; pc[1] = (b1 * iw1) / denom; pc[2] = (b2 * iw2) / denom; }
+                                const double* vary = d.vary + (size_t)bcast_u(cur.q[7].z, j) * d.K;
+                                if (d.kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(r_color, vary, pc);
+                                else if (d.kind == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
+                                else color = frag_eye(d.u, tex, vary, pc).bgra;
+                            }
                         }
-                    }
-                    zt[li] = z;                                                   // :191
-                    ct[li] = color;                                               // :192
-                    ++frags;                                                      // :194
-                    zmin = dmin(zmin, z); zmax = dmax(zmax, z);                   // :197-198
-                    if (z == 0.0 && !zero_locked) {       // rare: remember which signed zero came first
-                        unsigned long long order = ((unsigned long long)tri << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
-                        atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
+                        zt[li] = z;                                                   // :191
+                        ct[li] = color;                                               // :192
+                        ++frags;                                                      // :194
+                        zmin = dmin(zmin, z); zmax = dmax(zmax, z);                   // :197-198
+                        if (z == 0.0 && !zero_locked) {       // rare: remember which signed zero came first
+                            unsigned long long order = ((unsigned long long)tri << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
+                            atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
+                        }
                     }
                 }
             }
         }
+        cur = nxt;
     }
 
     // ---- tile out: row-contiguous stores --------------------------------------------------------
