@@ -1,0 +1,16 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for one round on the GPU box (run through gpurun from the repo root):
+#   bash profiles/run_rocprof.sh r01
+# 1) kernel trace + stats of the default bench workload, 2) separate PMC passes (FETCH_SIZE / WRITE_SIZE / LDS).
+set -e
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="bench.py --steps 3 --warmup 1 --cpu-sample 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/bench_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/bench_pmc_write.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/bench_pmc_sq.log 2>&1
+python3 profiles/summarize_rocprof.py $OUT > $OUT/summary.txt
+cat $OUT/summary.txt

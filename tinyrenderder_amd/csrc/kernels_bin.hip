@@ -148,9 +148,14 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
     }
     // bbox stats (our_gl.cpp:138-141): one set of atomics per wave
     int wx0 = wave_min_i(bx0), wy0 = wave_min_i(by0), wx1 = wave_max_i(bx1), wy1 = wave_max_i(by1);
+    // All waves hit the same four words, and same-address atomics serialise at ~11 ns each, so only
+    // issue one when it would change the value.  The plain loads may be stale, but min only falls and
+    // max only rises: a stale value can cause a redundant atomic, never a missed one.
     if ((threadIdx.x & 63) == 0 && wx0 != INT_MAX) {
-        atomicMin(&stats->min_x, wx0); atomicMin(&stats->min_y, wy0);
-        atomicMax(&stats->max_x, wx1); atomicMax(&stats->max_y, wy1);
+        if (wx0 < __builtin_nontemporal_load(&stats->min_x)) atomicMin(&stats->min_x, wx0);
+        if (wy0 < __builtin_nontemporal_load(&stats->min_y)) atomicMin(&stats->min_y, wy0);
+        if (wx1 > __builtin_nontemporal_load(&stats->max_x)) atomicMax(&stats->max_x, wx1);
+        if (wy1 > __builtin_nontemporal_load(&stats->max_y)) atomicMax(&stats->max_y, wy1);
     }
 }
 

@@ -386,8 +386,10 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
     }
     if (lane == 0 && frags) {
         atomicAdd(&stats->fragments, (unsigned long long)frags);
-        atomicMin(&stats->zmin_key, kmin);
-        atomicMax(&stats->zmax_key, kmax);
+        // same-address atomics serialise: skip the ones that cannot change the value (stale reads are safe,
+        // the keys only move one way)
+        if (kmin < __builtin_nontemporal_load(&stats->zmin_key)) atomicMin(&stats->zmin_key, kmin);
+        if (kmax > __builtin_nontemporal_load(&stats->zmax_key)) atomicMax(&stats->zmax_key, kmax);
     }
 }
 
