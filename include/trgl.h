@@ -182,6 +182,12 @@ int trgl_reset_phase_ms(trgl_ctx* ctx);
 /* Implementation traffic counters of the last flush: tri-tile pairs produced by binning. */
 int trgl_get_last_flush_info(trgl_ctx* ctx, uint64_t* triangles, uint64_t* pairs, uint64_t* tiles);
 
+/* Self-test of the kernel's two exactness shortcuts (division by the per-triangle constant u.z through a
+ * correctly rounded reciprocal + FMA corrections, and the division-free coverage signs) against the GPU's own
+ * IEEE fp64 division, on `samples` random and adversarial operand pairs (all-ones significands, quotients next to
+ * rounding midpoints, numerators next to u.z, signed zeros).  *mismatches must come back 0. */
+int trgl_selftest_division(trgl_ctx* ctx, uint64_t samples, uint64_t seed, uint64_t* mismatches);
+
 #ifdef __cplusplus
 }
 #endif

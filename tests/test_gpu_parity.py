@@ -146,3 +146,29 @@ def test_clear_between_frames_and_error_paths():
             ctx.draw(PHONG, clip, varyings=np.zeros((500, 24)))   # PHONG without uniforms
     with pytest.raises(TrglError):
         Context(0, 10, 3)
+
+
+def test_exact_division_shortcuts_selftest():
+    """k_raster divides by the per-triangle constant u.z with FMAs and decides coverage from signs; both must be
+    bit-identical to IEEE division.  2e9 random + adversarial operand pairs against the hardware divide."""
+    with Context(64, 64, 3) as ctx:
+        assert ctx.selftest_division(2_000_000_000, seed=12345) == 0
+
+
+def test_badly_scaled_triangles_take_the_literal_path():
+    """Vertices at 1e250 px (legal: the bbox clamp keeps the triangle) overflow the edge products; such triangles
+    are not 'well scaled' and must follow the reference's literal arithmetic (inf/NaN semantics included)."""
+    W = H = 128
+    clip, col = scenes.random_triangles(400, W, H, seed=31, rmin=4, rmax=64)
+    clip = clip.copy()
+    clip[::7, 0] = -1e250          # one vertex absurdly far left
+    clip[3::11, 5] = -1e200        # or far below
+    clip[5::13, 0:2] *= 1e-300     # or collapsing towards the origin (tiny edge deltas)
+    with Context(W, H, 3) as ctx:
+        ctx.draw(FLAT, clip, colors=col)
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    o = orc.Oracle(W, H, 3)
+    o.draw(orc.FLAT, clip, colors=col)
+    assert np.array_equal(z.view(np.uint64), o.z.view(np.uint64))
+    assert np.array_equal(fb, o.fb)
+    assert st == o.stats

@@ -27,6 +27,7 @@ SYMBOLS = [
     "trgl_write_framebuffer", "trgl_read_zbuffer", "trgl_write_zbuffer", "trgl_get_stats", "trgl_reset_stats",
     "trgl_format_stats", "trgl_framebuffer_device_ptr", "trgl_zbuffer_device_ptr", "trgl_stream", "trgl_set_stream",
     "trgl_set_profiling", "trgl_get_phase_ms", "trgl_reset_phase_ms", "trgl_get_last_flush_info",
+    "trgl_selftest_division",
 ]
 
 
@@ -114,6 +115,7 @@ def load_library(path: str = LIB_PATH):
     L.trgl_get_phase_ms.argtypes = [vp, dp, u64p]
     L.trgl_reset_phase_ms.argtypes = [vp]
     L.trgl_get_last_flush_info.argtypes = [vp, u64p, u64p, u64p]
+    L.trgl_selftest_division.argtypes = [vp, C.c_uint64, C.c_uint64, u64p]
     for name in SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int and name not in ("trgl_last_error",):
@@ -282,6 +284,11 @@ class Context:
 
     def reset_phase_ms(self):
         self._chk(self.L.trgl_reset_phase_ms(self.h))
+
+    def selftest_division(self, samples: int, seed: int = 1) -> int:
+        bad = C.c_uint64()
+        self._chk(self.L.trgl_selftest_division(self.h, samples, seed, C.byref(bad)))
+        return bad.value
 
     def last_flush_info(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -112,13 +112,27 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
             r.s0x = sx[2] - sx[0]; r.s0y = sx[1] - sx[0];                                  // :78
             r.s1x = sy[2] - sy[0]; r.s1y = sy[1] - sy[0];                                  // :79
             r.uz = r.s0x * r.s1y - r.s0y * r.s1x;                                          // :80 (cross().z)
+            // "Well scaled": every screen coordinate below 2^200 in magnitude, every edge delta zero or at
+            // least 2^-250, u.z negative (it is -cross_product) and not tiny.  Then no product, sum or
+            // quotient of the pixel loop can overflow, underflow or be NaN, which is what the division-free
+            // coverage test and the FMA division by u.z in k_raster rely on ("exactness").
+            {
+                const double BIG = 0x1p200, SMALL = 0x1p-250;
+                bool ws = r.uz < 0.0 && !(fabs(r.uz) < 1e-12);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) ws = ws && fabs(sx[q]) < BIG && fabs(sy[q]) < BIG;
+                const double dl[4] = { r.s0x, r.s0y, r.s1x, r.s1y };
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ws = ws && (dl[q] == 0.0 || fabs(dl[q]) >= SMALL);
+                r.ruz = ws ? 1.0 / r.uz : 0.0;
+            }
             r.z0 = ndc[2]; r.z1 = ndc[6]; r.z2 = ndc[10];
             r.iw0 = (fabs(v[3]) > 1e-12) ? (1.0 / v[3]) : 0.0;                             // :168-170
             r.iw1 = (fabs(v[7]) > 1e-12) ? (1.0 / v[7]) : 0.0;
             r.iw2 = (fabs(v[11]) > 1e-12) ? (1.0 / v[11]) : 0.0;
             r.bx0 = (uint16_t)bx0; r.by0 = (uint16_t)by0; r.bx1 = (uint16_t)bx1; r.by1 = (uint16_t)by1;
             r.color = d.colors ? d.colors[i] : 0xffffffffu;
-            r.draw = (uint32_t)draw_idx; r.local = i;
+            r.dl = ((uint32_t)draw_idx << 24) | i;
             // barycentric() rejects every pixel when |u.z| < 1e-12 (our_gl.cpp:82-83): no pairs then.
             // Rows outside this context's strip are not ours either.
             int y_lo = max(by0, fp.strip_y0), y_hi = min(by1, fp.strip_y1 - 1);

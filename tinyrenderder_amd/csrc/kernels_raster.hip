@@ -199,6 +199,18 @@ __device__ __forceinline__ double bcast_d(uint32_t lo, uint32_t hi, uint32_t j) 
     return __hiloint2double(__builtin_amdgcn_readlane((int)hi, (int)j), __builtin_amdgcn_readlane((int)lo, (int)j));
 }
 
+// a / uz, correctly rounded, for the per-triangle constant uz with ruz = RN(1/uz) (Markstein):
+// q0 = RN(a*ruz) is within 2 ulp of a/uz; one FMA residual step makes q1 faithful (error < 1 ulp),
+// and for a faithful q1 the second step q1 + (a - uz*q1)*ruz rounds to RN(a/uz) exactly.
+// Valid when nothing over/underflows: only used for "well scaled" triangles (see k_setup).
+__device__ __forceinline__ double div_by_uz(double a, double uz, double ruz) {
+    const double q0 = a * ruz;
+    const double e0 = __builtin_fma(-q0, uz, a);
+    const double q1 = __builtin_fma(e0, ruz, q0);
+    const double e1 = __builtin_fma(-q1, uz, a);
+    return __builtin_fma(e1, ruz, q1);
+}
+
 template <bool FLAT_ONLY>
 __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
@@ -269,12 +281,13 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
             const double r_ax = bcast_d(cur.q[0].x, cur.q[0].y, j), r_ay = bcast_d(cur.q[0].z, cur.q[0].w, j);
             const double r_s0x = bcast_d(cur.q[1].x, cur.q[1].y, j), r_s0y = bcast_d(cur.q[1].z, cur.q[1].w, j);
             const double r_s1x = bcast_d(cur.q[2].x, cur.q[2].y, j), r_s1y = bcast_d(cur.q[2].z, cur.q[2].w, j);
-            const double uz = bcast_d(cur.q[3].x, cur.q[3].y, j);
-            const double r_z0 = bcast_d(cur.q[3].z, cur.q[3].w, j), r_z1 = bcast_d(cur.q[4].x, cur.q[4].y, j),
-                         r_z2 = bcast_d(cur.q[4].z, cur.q[4].w, j);
-            const uint32_t bb0 = bcast_u(cur.q[6].z, j), bb1 = bcast_u(cur.q[6].w, j);
-            const uint32_t r_color = bcast_u(cur.q[7].x, j);
+            const double uz = bcast_d(cur.q[3].x, cur.q[3].y, j), ruz = bcast_d(cur.q[3].z, cur.q[3].w, j);
+            const double r_z0 = bcast_d(cur.q[4].x, cur.q[4].y, j), r_z1 = bcast_d(cur.q[4].z, cur.q[4].w, j),
+                         r_z2 = bcast_d(cur.q[5].x, cur.q[5].y, j);
+            const uint32_t bb0 = bcast_u(cur.q[7].x, j), bb1 = bcast_u(cur.q[7].y, j);
+            const uint32_t r_color = bcast_u(cur.q[7].z, j);
             const uint32_t tri = bcast_u(cur.tri, j);
+            const bool well_scaled = ruz != 0.0;          // wave-uniform
             const int x0 = max((int)(bb0 & 0xffff), px0), x1 = min((int)(bb1 & 0xffff), xa1);
             const int y0 = max((int)(bb0 >> 16), ya0), y1 = min((int)(bb1 >> 16), ya1);
             for (int by = y0; by <= y1; by += 8) {
@@ -286,10 +299,24 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                     const double s0z = r_ax - pxc, s1z = r_ay - pyc;
                     const double ux = r_s0y * s1z - s0z * r_s1y;                      // geometry.h:145
                     const double uy = s0z * r_s1x - r_s0x * s1z;                      // geometry.h:146
-                    const double b0 = 1.0 - (ux + uy) / uz;
-                    const double b1 = uy / uz;
-                    const double b2 = ux / uz;
-                    bool cov = act && !(b0 < 0 || b1 < 0 || b2 < 0);                  // :152
+                    const double us = ux + uy;
+                    double b0, b1, b2;
+                    bool cov;
+                    if (well_scaled) {
+                        // u.z < 0 and nothing can over/underflow, so the signs of the quotients are known
+                        // without dividing: u.y/u.z < 0 <=> u.y > 0, u.x/u.z < 0 <=> u.x > 0, and
+                        // 1 - RN(us/u.z) < 0 <=> RN(us/u.z) > 1 <=> us < u.z  ("exactness").
+                        cov = act && !(us < uz) && !(uy > 0.0) && !(ux > 0.0);        // :152
+                        if (__ballot(cov) == 0) continue;        // whole 8x8 block outside: no division at all
+                        b0 = 1.0 - div_by_uz(us, uz, ruz);
+                        b1 = div_by_uz(uy, uz, ruz);
+                        b2 = div_by_uz(ux, uz, ruz);
+                    } else {
+                        b0 = 1.0 - us / uz;                                           // :85, as written
+                        b1 = uy / uz;
+                        b2 = ux / uz;
+                        cov = act && !(b0 < 0 || b1 < 0 || b2 < 0);                   // :152
+                    }
                     const double z = b0 * r_z0 + b1 * r_z1 + b2 * r_z2;               // :156-158
                     cov = cov && __builtin_isfinite(z);                               // :160
                     if (__ballot(cov) == 0) continue;
@@ -300,18 +327,20 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                         if (FLAT_ONLY) {
                             color = r_color;
                         } else {
-                            const DrawDesc& d = draws[bcast_u(cur.q[7].y, j)];
+                            const uint32_t dl = bcast_u(cur.q[7].w, j);
+                            const DrawDesc& d = draws[dl >> 24];
                             if (d.kind == TRGL_SHADER_FLAT) {
                                 color = r_color;
                             } else {
-                                const double iw0 = bcast_d(cur.q[5].x, cur.q[5].y, j), iw1 = bcast_d(cur.q[5].z, cur.q[5].w, j),
-                                             iw2 = bcast_d(cur.q[6].x, cur.q[6].y, j);
+                                const uint32_t local = dl & 0xffffffu;
+                                const double iw0 = bcast_d(cur.q[5].z, cur.q[5].w, j), iw1 = bcast_d(cur.q[6].x, cur.q[6].y, j),
+                                             iw2 = bcast_d(cur.q[6].z, cur.q[6].w, j);
                                 double pc[3];
                                 const double denom = b0 * iw0 + b1 * iw1 + b2 * iw2;              // :172-174
                                 if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }  // :177-185
                                 else { pc[0] = (b0 * iw0) / denom; pc[1] = (b1 * iw1) / denom; pc[2] = (b2 * iw2) / denom; }
-                                const double* vary = d.vary + (size_t)bcast_u(cur.q[7].z, j) * d.K;
-                                if (d.kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(r_color, vary, pc);
+                                const double* vary = d.vary + (size_t)local * d.K;
+                                if (d.kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(d.colors ? d.colors[local] : 0xffffffffu, vary, pc);
                                 else if (d.kind == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
                                 else color = frag_eye(d.u, tex, vary, pc).bgra;
                             }
@@ -393,6 +422,54 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
     }
 }
 
+// ---- self-test of the two exactness shortcuts, against the hardware's IEEE division ------------------
+__device__ __forceinline__ unsigned long long sm64(unsigned long long& st) {
+    unsigned long long z = (st += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double mk_double(unsigned long long mant, int exp2, bool neg) {
+    unsigned long long bits = (mant & 0x000fffffffffffffull) | ((unsigned long long)(exp2 + 1023) << 52) | (neg ? 0x8000000000000000ull : 0ull);
+    return __longlong_as_double((long long)bits);
+}
+__global__ void k_selftest_division(unsigned long long n_per_thread, unsigned long long seed, unsigned long long* mismatches) {
+    unsigned long long st = seed + 0x1000003ull * (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x);
+    unsigned long long bad = 0;
+    for (unsigned long long it = 0; it < n_per_thread; ++it) {
+        unsigned long long r0 = sm64(st), r1 = sm64(st), r2 = sm64(st);
+        int mode = (int)(r2 & 7);
+        int eb = (int)((r2 >> 8) % 440) - 40;           // |uz| in [2^-40, 2^400): the well-scaled range
+        int ea = (int)((r2 >> 24) % 700) - 350;
+        unsigned long long mb = r1;
+        if (mode == 1) mb = 0x000fffffffffffffull;                       // all-ones significand
+        if (mode == 2) mb = 0x000fffffffffffffull ^ (1ull << (r1 % 52));  // one zero bit
+        if (mode == 3) mb = 0;                                           // power of two
+        double uz = mk_double(mb, eb, true);                             // u.z < 0
+        double a = mk_double(r0, ea, (r2 >> 40) & 1);
+        if (mode >= 4 && mode <= 6) {
+            // numerator chosen so that a/uz lies next to a rounding midpoint: a = RN(uz * (q + ulp(q)/2 * (1 +- tiny)))
+            double q = mk_double(r0, ea - eb, (r2 >> 41) & 1);
+            double half_ulp = mk_double(0, ea - eb - 53, false);
+            a = __builtin_fma(uz, q, uz * half_ulp);
+            if (mode == 5) a = __longlong_as_double(__double_as_longlong(a) + 1);
+            if (mode == 6) a = __longlong_as_double(__double_as_longlong(a) - 1);
+        }
+        if (mode == 7) a = (r2 >> 42) & 1 ? 0.0 : -0.0;
+        double ruz = 1.0 / uz;
+        double ref = a / uz, got = div_by_uz(a, uz, ruz);
+        if (__double_as_longlong(ref) != __double_as_longlong(got)) ++bad;
+        // sign shortcuts of the coverage test
+        if ((ref < 0) != (a > 0.0)) ++bad;
+        if (((1.0 - ref) < 0) != (a < uz)) ++bad;
+        // numerator right next to uz, where 1 - q changes sign
+        double a2 = __longlong_as_double(__double_as_longlong(uz) + (long long)(r1 % 5) - 2);
+        double ref2 = a2 / uz;
+        if (__double_as_longlong(ref2) != __double_as_longlong(div_by_uz(a2, uz, ruz))) ++bad;
+        if (((1.0 - ref2) < 0) != (a2 < uz)) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 // after the raster kernel of a flush: fix the sign of a zero z-range end (see DevStats)
 __global__ void k_fold_stats(DevStats* __restrict__ s) {
     if (!s->zero_locked && (s->zero_pos_key != TRGL_ZERO_KEY_EMPTY || s->zero_neg_key != TRGL_ZERO_KEY_EMPTY)) {
@@ -406,6 +483,10 @@ __global__ void k_fold_stats(DevStats* __restrict__ s) {
 }  // namespace
 
 namespace trgl {
+
+void launch_selftest_division(hipStream_t s, unsigned long long n_per_thread, unsigned long long seed, unsigned long long* mismatches) {
+    hipLaunchKernelGGL(k_selftest_division, dim3(1024), dim3(256), 0, s, n_per_thread, seed, mismatches);
+}
 
 void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const TriRec* recs, const uint32_t* vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,

@@ -25,4 +25,7 @@ void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const T
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
                    const DevTexture* tex, DevStats* stats);
 
+void launch_selftest_division(hipStream_t s, unsigned long long n_per_thread, unsigned long long seed,
+                              unsigned long long* mismatches);
+
 }  // namespace trgl

@@ -265,22 +265,29 @@ int trgl_draw(trgl_ctx* c, int kind, const trgl_uniforms* u, const double* clip,
     if (mem_kind != TRGL_MEM_HOST && mem_kind != TRGL_MEM_DEVICE) return fail(c, TRGL_E_INVALID, "trgl_draw: bad mem_kind");
     if (c->queued_tris + n > 0xffffffffull) { int r = trgl_flush(c); if (r) return r; }
     if (n > 0xffffffffull) return fail(c, TRGL_E_UNSUPPORTED, "trgl_draw: more than 2^32-1 triangles in one draw");
-    if (c->draws.size() >= TRGL_MAX_DRAWS) { int r = trgl_flush(c); if (r) return r; }
 
-    DrawDesc d; std::memset(&d, 0, sizeof(d));
-    d.n = (uint32_t)n; d.first = (uint32_t)c->queued_tris; d.kind = kind; d.K = K;
-    if (u) d.u = *u; else { d.u.tex_diffuse = d.u.tex_normal = d.u.tex_specular = -1; }
-    if (mem_kind == TRGL_MEM_DEVICE) {
-        d.clip = clip; d.vary = K ? vary : nullptr; d.colors = colors;
-    } else {
+    const double* dclip = clip; const double* dvary = K ? vary : nullptr; const uint32_t* dcol = colors;
+    if (mem_kind == TRGL_MEM_HOST) {
         void* p = nullptr; int r;
         if ((r = stage_copy(c, clip, n * 12 * sizeof(double), &p))) return r;
-        d.clip = (const double*)p;
-        if (K) { if ((r = stage_copy(c, vary, n * K * sizeof(double), &p))) return r; d.vary = (const double*)p; }
-        if (colors) { if ((r = stage_copy(c, colors, n * sizeof(uint32_t), &p))) return r; d.colors = (const uint32_t*)p; }
+        dclip = (const double*)p;
+        if (K) { if ((r = stage_copy(c, vary, n * K * sizeof(double), &p))) return r; dvary = (const double*)p; }
+        if (colors) { if ((r = stage_copy(c, colors, n * sizeof(uint32_t), &p))) return r; dcol = (const uint32_t*)p; }
     }
-    c->draws.push_back(d);
-    c->queued_tris += n;
+    // a record addresses its triangle as (draw index, 24-bit index): split larger submissions
+    for (uint64_t done = 0; done < n;) {
+        uint64_t m = n - done; if (m > TRGL_DRAW_MAX_TRIS) m = TRGL_DRAW_MAX_TRIS;
+        if (c->draws.size() >= TRGL_MAX_DRAWS) { int r = trgl_flush(c); if (r) return r; }
+        DrawDesc d; std::memset(&d, 0, sizeof(d));
+        d.n = (uint32_t)m; d.first = (uint32_t)c->queued_tris; d.kind = kind; d.K = K;
+        if (u) d.u = *u; else { d.u.tex_diffuse = d.u.tex_normal = d.u.tex_specular = -1; }
+        d.clip = dclip + done * 12;
+        d.vary = dvary ? dvary + done * K : nullptr;
+        d.colors = dcol ? dcol + done : nullptr;
+        c->draws.push_back(d);
+        c->queued_tris += m;
+        done += m;
+    }
     return TRGL_OK;
 }
 
@@ -470,6 +477,23 @@ int trgl_format_stats(const trgl_stats* s, char* buf, size_t buflen) {   // our_
 void* trgl_framebuffer_device_ptr(trgl_ctx* c) { return c ? c->fb : nullptr; }
 void* trgl_zbuffer_device_ptr(trgl_ctx* c) { return c ? c->zb : nullptr; }
 void* trgl_stream(trgl_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int trgl_selftest_division(trgl_ctx* c, uint64_t samples, uint64_t seed, uint64_t* mismatches) {
+    CHKCTX(c);
+    if (!mismatches) return fail(c, TRGL_E_INVALID, "null mismatches");
+    int r = trgl_flush(c); if (r) return r;
+    unsigned long long* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, 8));
+    HIPCHK(c, hipMemsetAsync(d, 0, 8, c->stream));
+    unsigned long long per_thread = (samples + 1024ull * 256 - 1) / (1024ull * 256);
+    launch_selftest_division(c->stream, per_thread, seed, d);
+    unsigned long long h = 0;
+    HIPCHK(c, hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d));
+    *mismatches = h;
+    return TRGL_OK;
+}
 
 int trgl_set_stream(trgl_ctx* c, void* hip_stream) {
     CHKCTX(c);

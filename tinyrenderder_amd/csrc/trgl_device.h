@@ -24,14 +24,16 @@ struct alignas(128) TriRec {
     double s0x, s0y;          // C.x - A.x, B.x - A.x            (our_gl.cpp:78)
     double s1x, s1y;          // C.y - A.y, B.y - A.y            (our_gl.cpp:79)
     double uz;                // s0x*s1y - s0y*s1x = cross().z   (our_gl.cpp:80, geometry.h:147)
+    double ruz;               // RN(1/uz) when the triangle is "well scaled" (see setup), else 0:
+                              // lets the pixel loop divide by uz with FMAs, bit-identically
     double z0, z1, z2;        // NDC z of the three vertices     (our_gl.cpp:156-158)
     double iw0, iw1, iw2;     // |w|>1e-12 ? 1/w : 0             (our_gl.cpp:168-170)
     uint16_t bx0, by0, bx1, by1;   // clamped pixel bbox, inclusive (our_gl.cpp:130-133)
-    uint32_t color;           // FLAT / GOURAUD packed BGRA
-    uint32_t draw;            // index into the flush's draw table
-    uint32_t local;           // triangle index inside its draw (varyings = draw.vary + local*K)
+    uint32_t color;           // FLAT packed BGRA (GOURAUD reads its base colour through `dl`)
+    uint32_t dl;              // draw index << 24 | triangle index inside its draw (< 2^24)
 };
 static_assert(sizeof(TriRec) == 128, "TriRec must be one 128-B line");
+#define TRGL_DRAW_MAX_TRIS (1u << 24)   // triangles per DrawDesc; trgl_draw splits larger submissions
 
 struct DevTexture {
     const uint8_t* data;
