@@ -9,12 +9,11 @@ out = sys.argv[1]
 
 
 def short(name):
-    name = name.split("(")[0]
-    for k in ("k_raster<true>", "k_raster<false>", "k_raster", "k_setup", "k_scan_reduce", "k_scan_spine", "k_scan_apply", "k_expand",
-              "k_radix_hist", "k_radix_scatter", "k_bounds", "k_fold_stats"):
-        if k.replace("<true>", "ILb1").replace("<false>", "ILb0") in name or k in name:
+    for k in ("k_raster<true>", "k_raster<false>", "k_setup", "k_scan_reduce", "k_scan_spine", "k_scan_apply", "k_expand",
+              "k_radix_hist", "k_radix_scatter", "k_bounds", "k_fold_stats", "k_selftest_division"):
+        if k in name:
             return k
-    return name[:60]
+    return name.split("(")[0][:60]
 
 
 print("== kernel trace stats (rocprofv3 --kernel-trace --stats) ==")
