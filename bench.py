@@ -65,7 +65,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from tinyrenderder_amd import scenes
+    from tinyrenderder_amd import scenes, shard
     from tinyrenderder_amd.api import Context, FLAT, PHASE_RASTER, PHASE_SETUP, PHASE_BIN, PHASE_TOTAL
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,11 +89,9 @@ def main():
 
     ctx = Context(W, H, 3, device=local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)          # order with torch / RCCL on one stream
-    rows = H // world
-    y0, y1 = rank * rows, (rank + 1) * rows if rank < world - 1 else H
+    y0, y1 = shard.strip_rows(H, world, rank)
     full_fb = None
     if world > 1:
-        assert H % world == 0, "equal strips needed for the in-place all-gather"
         ctx.set_strip(y0, y1)
         full_fb = torch.as_tensor(_DevBuf(ctx.framebuffer_ptr, W * H * 3), device="cuda")
 
@@ -102,7 +100,7 @@ def main():
         ctx.draw(FLAT, dclip, colors=dcol, device=True)
         ctx.flush()
         if world > 1:   # join the colour strips: every rank ends with the whole TGAImage buffer
-            dist.all_gather_into_tensor(full_fb, full_fb[y0 * W * 3: y1 * W * 3])
+            shard.gather_strips(full_fb, W, H, 3, rank, world)
 
     def fence():
         if world > 1:

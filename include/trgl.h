@@ -182,6 +182,14 @@ int trgl_reset_phase_ms(trgl_ctx* ctx);
 /* Implementation traffic counters of the last flush: tri-tile pairs produced by binning. */
 int trgl_get_last_flush_info(trgl_ctx* ctx, uint64_t* triangles, uint64_t* pairs, uint64_t* tiles);
 
+/* ---- TGA writer (host only) ------------------------------------------------ */
+
+/* Replaces: TGAImage::write_tga_file(name, vflip, rle) (tgaimage.cpp:161-242): produces exactly the bytes the
+ * reference writes — 18-byte header (tgaimage.h:10-25), no footer, its RLE packetisation.  `out` needs
+ * trgl_tga_max_size(w,h,bpp) bytes; *out_len receives the file length.  Needs no GPU and no context. */
+size_t trgl_tga_max_size(int w, int h, int bpp);
+int trgl_tga_encode(const uint8_t* pixels, int w, int h, int bpp, int vflip, int rle, uint8_t* out, size_t* out_len);
+
 /* Self-test of the kernel's two exactness shortcuts (division by the per-triangle constant u.z through a
  * correctly rounded reciprocal + FMA corrections, and the division-free coverage signs) against the GPU's own
  * IEEE fp64 division, on `samples` random and adversarial operand pairs (all-ones significands, quotients next to

@@ -85,6 +85,8 @@ def lib():
         L.orc_normalized3.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_mat4_mul_dir.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_interp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_tga_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_tga_encode.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -211,3 +213,25 @@ def format_stats_line(stats_tuple) -> str:
     lo = f"{zlo:.6f}" if np.isfinite(zlo) else "inf"
     hi = f"{zhi:.6f}" if np.isfinite(zhi) else "-inf"
     return f"DEBUG: triangles={tri} fragments_drawn={frag} bbox=[{x0},{y0}] - [{x1},{y1}] z-range=[{lo},{hi}]"
+
+
+def tga_encode(img: np.ndarray, vflip=True, rle=True) -> bytes:
+    """TGAImage::write_tga_file bytes for an [h,w,bpp] uint8 image, via the C restatement."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, bpp = img.shape
+    out = np.empty(18 + img.size + w * h + 16, np.uint8)
+    n = lib().orc_tga_encode(img.ctypes.data, w, h, bpp, int(vflip), int(rle), out.ctypes.data)
+    return out[:n].tobytes()
+
+
+def run_reference_tga(img: np.ndarray, vflip=True, rle=True) -> bytes:
+    """The file the reference's own TGAImage::write_tga_file writes (build container only)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, bpp = img.shape
+    with tempfile.TemporaryDirectory() as d:
+        ip, op = os.path.join(d, "in.bin"), os.path.join(d, "out.tga")
+        with open(ip, "wb") as f:
+            f.write(struct.pack("<6i", w, h, bpp, int(vflip), int(rle), 0))
+            f.write(img.tobytes())
+        subprocess.run([REF_HARNESS, "tga", ip, op], check=True)
+        return open(op, "rb").read()

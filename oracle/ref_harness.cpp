@@ -180,11 +180,23 @@ int run_vecops(const char* in_path, const char* out_path) {
     return out ? 0 : 3;
 }
 
+// tga: input = int32 w,h,bpp,vflip,rle,pad + pixel bytes; output = the file TGAImage::write_tga_file produces.
+int run_tga(const char* in_path, const char* out_path) {
+    Reader r;
+    if (!r.load(in_path)) return 2;
+    int w = r.get<int32_t>(), h = r.get<int32_t>(), bpp = r.get<int32_t>(), vflip = r.get<int32_t>(), rle = r.get<int32_t>();
+    r.get<int32_t>();
+    TGAImage img(w, h, bpp);
+    std::memcpy(img.buffer(), r.take((size_t)w * h * bpp), (size_t)w * h * bpp);
+    return img.write_tga_file(out_path, vflip != 0, rle != 0) ? 0 : 3;      // tgaimage.cpp:161-191
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
     if (argc == 4 && std::strcmp(argv[1], "scene") == 0) return run_scene(argv[2], argv[3]);
     if (argc == 4 && std::strcmp(argv[1], "vecops") == 0) return run_vecops(argv[2], argv[3]);
-    std::fprintf(stderr, "usage: ref_harness scene|vecops <in> <out>\n");
+    if (argc == 4 && std::strcmp(argv[1], "tga") == 0) return run_tga(argv[2], argv[3]);
+    std::fprintf(stderr, "usage: ref_harness scene|vecops|tga <in> <out>\n");
     return 1;
 }

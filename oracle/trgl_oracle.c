@@ -387,3 +387,46 @@ uint64_t orc_fnv1a64(const void* p, uint64_t nbytes) {
     for (uint64_t i = 0; i < nbytes; ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
     return h;
 }
+
+/* TGAImage::write_tga_file + unload_rle_data — tgaimage.cpp:161-242 */
+uint64_t orc_tga_encode(const uint8_t* data, int w, int h, int bpp, int vflip, int rle, uint8_t* out) {
+    uint64_t n = 0;
+    memset(out, 0, 18);                                   /* TGAHeader header = {} (tgaimage.h:10-25, packed) */
+    out[2] = (uint8_t)(bpp == 1 ? (rle ? 11 : 3) : (rle ? 10 : 2));   /* datatypecode :175 */
+    out[12] = (uint8_t)(w & 0xff); out[13] = (uint8_t)((w >> 8) & 0xff);
+    out[14] = (uint8_t)(h & 0xff); out[15] = (uint8_t)((h >> 8) & 0xff);
+    out[16] = (uint8_t)(bpp * 8);                          /* :169 */
+    out[17] = vflip ? 0x00 : 0x20;                         /* :176 */
+    n = 18;
+    if (!rle) { memcpy(out + n, data, (size_t)w * h * bpp); return n + (uint64_t)w * h * bpp; }
+    const int max_chunk_length = 128;                      /* :194 */
+    int npixels = w * h, cur = 0;
+    while (cur < npixels) {                                /* :198 */
+        int chunkstart = cur * bpp, run_length = 1, raw = 1;
+        while (cur + run_length < npixels && run_length < max_chunk_length) {     /* :203-213 */
+            int equal = 1;
+            for (int i = 0; i < bpp; i++) if (data[(cur + run_length) * bpp + i] != data[chunkstart + i]) { equal = 0; break; }
+            if (!equal) break;
+            run_length++; raw = 0;
+        }
+        if (!raw) {                                        /* :215-220 */
+            out[n++] = (uint8_t)(run_length - 1 + 128);
+            memcpy(out + n, data + chunkstart, bpp); n += bpp;
+            cur += run_length;
+        } else {                                           /* :221-238 */
+            int rawstart = cur;
+            run_length = 1;
+            while (rawstart + run_length < npixels && run_length < max_chunk_length) {
+                int next_equal = 1;
+                for (int i = 0; i < bpp; i++)
+                    if (data[(rawstart + run_length) * bpp + i] != data[(rawstart + run_length - 1) * bpp + i]) { next_equal = 0; break; }
+                if (next_equal) break;
+                run_length++;
+            }
+            out[n++] = (uint8_t)(run_length - 1);
+            memcpy(out + n, data + rawstart * bpp, (size_t)run_length * bpp); n += (uint64_t)run_length * bpp;
+            cur += run_length;
+        }
+    }
+    return n;
+}

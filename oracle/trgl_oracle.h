@@ -59,6 +59,10 @@ void orc_normalized3(const double v[3], double out[3]);                       /*
 void orc_mat4_mul_dir(const double m[16], const double n[3], double out[3]);  /* geometry.h:186-192, w=0 */
 void orc_interp(const double* v0, const double* v1, const double* v2, const double b[3], int n, double* out);
 
+/* The bytes TGAImage::write_tga_file(name, vflip, rle) writes (tgaimage.cpp:161-242, header tgaimage.h:10-25).
+ * out must hold 18 + w*h*bpp + w*h bytes (worst case); returns the length. */
+uint64_t orc_tga_encode(const uint8_t* data, int w, int h, int bpp, int vflip, int rle, uint8_t* out);
+
 /* FNV-1a 64 over raw bytes (used for fixtures) */
 uint64_t orc_fnv1a64(const void* p, uint64_t nbytes);
 

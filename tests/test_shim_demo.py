@@ -1,0 +1,69 @@
+"""The main.cpp-shaped C++ demo (examples/demo_main.cpp) over the shim headers, against the CPU oracle replaying
+the same sequence of passes (head PHONG, z-buffer save, EYE pass, z-buffer restore, flat overlay)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from tinyrenderder_amd import scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "examples", "demo_main")
+
+
+def _write_model(path, W, H, bpp, hd, strength, textures, fclip, fcol):
+    with open(path, "wb") as f:
+        nf = hd["positions"].shape[0]
+        f.write(b"TRGMDL01")
+        f.write(struct.pack("<4i", W, H, bpp, nf))
+        f.write(np.asarray(hd["model_view"], np.float64).tobytes())
+        f.write(np.asarray(hd["projection"], np.float64).tobytes())
+        for k in ("key", "fill", "rim"):
+            f.write(np.asarray(hd["world_lights"][k], np.float64).tobytes())
+        f.write(struct.pack("<d", strength))
+        for k in ("positions", "normals", "uvs"):
+            f.write(np.ascontiguousarray(hd[k], np.float64).tobytes())
+        for t in textures:
+            t = np.ascontiguousarray(t, np.uint8)
+            f.write(struct.pack("<4i", t.shape[1], t.shape[0], t.shape[2], 0))
+            b = t.tobytes()
+            f.write(b + b"\0" * ((8 - len(b) % 8) % 8))
+        f.write(struct.pack("<ii", fclip.shape[0], 0))
+        f.write(fclip.tobytes())
+        f.write(fcol.tobytes())
+
+
+@pytest.mark.gpu
+def test_main_cpp_shaped_demo_matches_oracle(tmp_path):
+    assert os.path.exists(DEMO), "examples/demo_main not built: run __graft_entry__.build()"
+    W, H, bpp = 320, 240, 3
+    hd = scenes.head_standin(3, W, H)
+    d, n, s = scenes.procedural_textures(128)
+    fclip, fcol = scenes.random_triangles(300, W, H, seed=8, rmin=2, rmax=20)
+    model, out, tga = tmp_path / "model.bin", tmp_path / "out.bin", tmp_path / "out.tga"
+    _write_model(model, W, H, bpp, hd, 0.75, (d, n, s), fclip, fcol)
+    r = subprocess.run([DEMO, str(model), str(out), str(tga)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = open(out, "rb").read()
+    fb = np.frombuffer(raw, np.uint8, W * H * bpp).reshape(H, W, bpp)
+    z = np.frombuffer(raw, np.float64, W * H, W * H * bpp).reshape(H, W)
+    line = raw[W * H * bpp + W * H * 8:].decode().strip()
+
+    o = orc.Oracle(W, H, bpp)
+    for slot, t in enumerate((d, n, s)):
+        o.upload_texture(slot, t)
+    args = (hd["model_view"], hd["key"], hd["fill"], hd["rim"])
+    o.draw(orc.PHONG, hd["clip"], hd["varyings"], uniforms=orc.make_uniforms(*args, 0.75, 0, 1, 2))
+    z_before = o.z.copy()
+    o.draw(orc.EYE, hd["clip"][::3], hd["varyings"][::3], uniforms=orc.make_uniforms(*args, 1.0, 0, -1, 2))
+    o.z[...] = z_before                                   # main.cpp:730
+    o.draw(orc.FLAT, fclip, colors=fcol)
+    assert np.array_equal(z.view(np.uint64), o.z.view(np.uint64))
+    d8 = np.abs(fb.astype(np.int16) - o.fb.astype(np.int16))
+    assert d8.max() <= 1 and (d8.max(axis=-1) > 0).mean() <= 1e-3      # EYE pass: pow tolerance (see test_gpu_parity)
+    assert line == orc.format_stats_line(o.stats)
+    assert r.stderr.strip().endswith(line)                # print_render_stats() wrote the same line to stderr
+    assert open(tga, "rb").read() == orc.tga_encode(fb)   # the written file is what the reference writer would emit

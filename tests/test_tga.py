@@ -1,0 +1,49 @@
+"""TGA writer: product encoder vs golden file hashes written by the reference's own
+TGAImage::write_tga_file (tests/golden/tga_golden.json, made with oracle/_ref), and vs the C restatement."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import orc
+from tinyrenderder_amd import api
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "tga_golden.json")))
+
+
+def _image(name):
+    if name == "tga_runs":
+        return np.load(os.path.join(HERE, "golden", "tga_runs_input.npy"))
+    return cases.run_oracle(cases.CASES[name]())[0]     # any deterministic image will do; this one is what the reference saw
+
+
+@pytest.mark.parametrize("key", sorted(GOLD))
+def test_tga_bytes_match_reference_writer(key):
+    name, flags = key.split("|")
+    vflip, rle = flags[0] == "1", flags[1] == "1"
+    img = _image(name)
+    got = api.tga_encode(img, vflip, rle)
+    assert len(got) == GOLD[key]["length"]
+    assert hashlib.sha256(got).hexdigest() == GOLD[key]["sha256"]
+    assert got == orc.tga_encode(img, vflip, rle)
+
+
+def test_tga_header_layout():
+    img = np.zeros((5, 7, 3), np.uint8)
+    b = api.tga_encode(img, vflip=True, rle=False)
+    assert len(b) == 18 + 5 * 7 * 3                       # no footer (tgaimage.cpp:161-191)
+    assert b[2] == 2 and b[12] == 7 and b[14] == 5 and b[16] == 24 and b[17] == 0x00
+    assert api.tga_encode(img, vflip=False, rle=True)[17] == 0x20 and api.tga_encode(img[..., :1], rle=True)[2] == 11
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not orc.ref_available(), reason="oracle/_ref not built (reference tree absent)")
+def test_tga_random_images_against_reference_binary():
+    rng = np.random.default_rng(5)
+    for bpp in (1, 3, 4):
+        img = (rng.integers(0, 3, size=(37, 53, bpp)) * 120).astype(np.uint8)     # few colours: lots of runs
+        assert api.tga_encode(img) == orc.run_reference_tga(img)

@@ -27,7 +27,7 @@ SYMBOLS = [
     "trgl_write_framebuffer", "trgl_read_zbuffer", "trgl_write_zbuffer", "trgl_get_stats", "trgl_reset_stats",
     "trgl_format_stats", "trgl_framebuffer_device_ptr", "trgl_zbuffer_device_ptr", "trgl_stream", "trgl_set_stream",
     "trgl_set_profiling", "trgl_get_phase_ms", "trgl_reset_phase_ms", "trgl_get_last_flush_info",
-    "trgl_selftest_division",
+    "trgl_selftest_division", "trgl_tga_max_size", "trgl_tga_encode",
 ]
 
 
@@ -116,6 +116,9 @@ def load_library(path: str = LIB_PATH):
     L.trgl_reset_phase_ms.argtypes = [vp]
     L.trgl_get_last_flush_info.argtypes = [vp, u64p, u64p, u64p]
     L.trgl_selftest_division.argtypes = [vp, C.c_uint64, C.c_uint64, u64p]
+    L.trgl_tga_max_size.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.trgl_tga_max_size.restype = C.c_size_t
+    L.trgl_tga_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_size_t)]
     for name in SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int and name not in ("trgl_last_error",):
@@ -133,6 +136,21 @@ def _ptr(a):
     if hasattr(a, "data_ptr"):
         return a.data_ptr()
     return a.ctypes.data
+
+
+def tga_encode(img, vflip: bool = True, rle: bool = True) -> bytes:
+    """The bytes the reference's TGAImage::write_tga_file would write for an [h,w,bpp] uint8 image (host only)."""
+    L = load_library()
+    img = np.ascontiguousarray(img, np.uint8)
+    if img.ndim == 2:
+        img = img[..., None]
+    h, w, bpp = img.shape
+    out = np.empty(L.trgl_tga_max_size(w, h, bpp), np.uint8)
+    n = C.c_size_t()
+    rc = L.trgl_tga_encode(img.ctypes.data, w, h, bpp, int(vflip), int(rle), out.ctypes.data, C.byref(n))
+    if rc != 0:
+        raise TrglError(f"trgl_tga_encode failed ({rc})")
+    return out[:n.value].tobytes()
 
 
 class Context:

@@ -16,6 +16,7 @@
 #include "../../include/trgl.h"
 #include "launch.h"
 #include "trgl_device.h"
+#include "../shim/trgl_image.h"
 
 using namespace trgl;
 
@@ -477,6 +478,21 @@ int trgl_format_stats(const trgl_stats* s, char* buf, size_t buflen) {   // our_
 void* trgl_framebuffer_device_ptr(trgl_ctx* c) { return c ? c->fb : nullptr; }
 void* trgl_zbuffer_device_ptr(trgl_ctx* c) { return c ? c->zb : nullptr; }
 void* trgl_stream(trgl_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+size_t trgl_tga_max_size(int w, int h, int bpp) {
+    if (w <= 0 || h <= 0 || bpp <= 0) return 18;
+    return size_t(18) + size_t(w) * h * bpp + size_t(w) * h;      // every pixel its own literal packet
+}
+
+int trgl_tga_encode(const uint8_t* pixels, int w, int h, int bpp, int vflip, int rle, uint8_t* out, size_t* out_len) {
+    if (!pixels || !out || !out_len || w <= 0 || h <= 0 || w > 65535 || h > 65535 || !(bpp == 1 || bpp == 3 || bpp == 4)) return TRGL_E_INVALID;
+    TGAImage img(w, h, bpp);
+    std::memcpy(img.buffer(), pixels, size_t(w) * h * bpp);
+    std::vector<uint8_t> bytes = img.encode_tga(vflip != 0, rle != 0);
+    std::memcpy(out, bytes.data(), bytes.size());
+    *out_len = bytes.size();
+    return TRGL_OK;
+}
 
 int trgl_selftest_division(trgl_ctx* c, uint64_t samples, uint64_t seed, uint64_t* mismatches) {
     CHKCTX(c);

@@ -221,9 +221,13 @@ def head_standin(level: int, width: int, height: int, seed: int = SEED_DEFAULT, 
     def light(d):
         d = np.asarray(d, np.float64)
         d = _normalize_rows(d)                                     # main.cpp:615-617
-        e = np.array([(mv[r, 0] * d[0] + mv[r, 1] * d[1]) + mv[r, 2] * d[2] for r in range(3)])
+        e = np.array([((0.0 + mv[r, 0] * d[0]) + mv[r, 1] * d[1]) + mv[r, 2] * d[2] for r in range(3)])
         return _normalize_rows(e)                                  # main.cpp:59-68
-    return dict(clip=np.ascontiguousarray(clip), varyings=np.ascontiguousarray(varyings), model_view=mv,
+    world = {k: _normalize_rows(np.asarray(v, np.float64)) for k, v in
+             dict(key=[1.0, 1.4, 1.0], fill=[-0.3, 0.5, 0.2], rim=[-1.0, 0.8, -1.5]).items()}
+    return dict(clip=np.ascontiguousarray(clip), varyings=np.ascontiguousarray(varyings), model_view=mv, projection=proj,
+                positions=np.ascontiguousarray(pos), normals=np.ascontiguousarray(nrm), uvs=np.ascontiguousarray(uv),
+                world_lights=world,
                 key=light([1.0, 1.4, 1.0]), fill=light([-0.3, 0.5, 0.2]), rim=light([-1.0, 0.8, -1.5]))
 
 

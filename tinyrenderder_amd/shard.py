@@ -1,0 +1,45 @@
+"""Multi-GPU sharding of the rasterize() path: horizontal screen strips joined by ONE all-gather.
+
+Rank r of G owns framebuffer rows [r*H/G, (r+1)*H/G): a contiguous byte range of the row-major TGAImage buffer and
+of the z-buffer, so the gather is an in-place all_gather_into_tensor (RCCL over xGMI on GPUs; gloo in the CPU
+tests).  Every rank streams the whole triangle list through setup (96 B/triangle of HBM reads is cheaper than
+moving 128-B records over xGMI links) and rasterizes only its rows.  The reference's counters shard cleanly:
+fragments_drawn adds up, the z range is a min/max, and triangle/bbox counters are identical on every rank.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def strip_rows(height: int, world: int, rank: int):
+    """Rows [y0, y1) of rank `rank`.  Equal strips (the in-place all-gather needs equal chunks)."""
+    if height % world:
+        raise ValueError(f"height {height} is not divisible by {world} ranks: equal strips are required")
+    rows = height // world
+    return rank * rows, (rank + 1) * rows
+
+
+def gather_strips(full, width: int, height: int, bytes_per_pixel: int, rank: int, world: int, group=None):
+    """In-place all-gather: `full` is a flat uint8 tensor of the whole buffer whose own strip is already written."""
+    import torch.distributed as dist
+    y0, y1 = strip_rows(height, world, rank)
+    chunk = full[y0 * width * bytes_per_pixel: y1 * width * bytes_per_pixel]
+    dist.all_gather_into_tensor(full, chunk, group=group)
+    return full
+
+
+def reduce_stats(stats, device=None, group=None):
+    """Combine per-rank trgl stats tuples (api.Stats.astuple()) into the whole-frame tuple.
+    (The sign of a zero z-range end follows the first zero in submission order on ONE rank only; across ranks the
+    merged value is the numeric min/max — DESIGN.md, multi-GPU.)"""
+    import torch
+    import torch.distributed as dist
+    tri, frag, x0, y0, x1, y1, zlo, zhi = stats[:8]
+    s = torch.tensor([frag], dtype=torch.int64, device=device)
+    lo = torch.tensor([zlo], dtype=torch.float64, device=device)
+    hi = torch.tensor([zhi], dtype=torch.float64, device=device)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    zlo, zhi = float(lo.item()), float(hi.item())
+    return (tri, int(s.item()), x0, y0, x1, y1, zlo, zhi, float(np.copysign(1.0, zlo)), float(np.copysign(1.0, zhi)))

@@ -1,0 +1,208 @@
+// trgl_gl.h — the reference's our_gl.h surface (our_gl.h:17-61) over the C ABI of include/trgl.h.
+//
+// Same names, argument meaning and (silent) error behaviour as the reference:
+//   globals  ModelView / Perspective / Viewport / zbuffer        (our_gl.h:17-20)
+//   lookat, init_perspective, init_viewport, init_zbuffer        (our_gl.h:25-31)
+//   struct IShader, typedef Triangle, rasterize(), print_render_stats()  (our_gl.h:36-61)
+// What changes for a caller, and why:
+//   * rasterize() is DEFERRED: it snapshots the clip coordinates, the shader's varyings and the uniforms that can
+//     change between calls (the global ModelView is read inside fragment(), main.cpp:116) and batches them; the GPU
+//     runs them in submission order at gl_flush().  Call gl_flush(framebuffer) before touching `zbuffer` or the
+//     framebuffer's pixels (the reference does so at main.cpp:700,730,743,751,759,773).
+//   * a C++ virtual cannot be called from a kernel: IShader gains describe(), returning the POD descriptor of a
+//     shader kind the device implements (trgl_shaders.h: FlatShader, GouraudShader, PhongShader, EyeShader).
+//     A subclass without one makes rasterize() fail loudly — there is NO CPU fallback.
+// Header-only (C++17 inline variables); link with -ltrgl.
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <utility>
+#include <vector>
+
+#include "../../include/trgl.h"
+#include "trgl_geometry.h"
+#include "trgl_image.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+inline mat<4, 4> ModelView = mat<4, 4>::identity();
+inline mat<4, 4> Perspective = mat<4, 4>::identity();
+inline mat<4, 4> Viewport = mat<4, 4>::identity();
+inline std::vector<double> zbuffer;
+
+// What a shader hands to the device: kind + uniforms + this triangle's varyings/colour (include/trgl.h).
+struct trgl_shader_desc {
+    int kind = TRGL_SHADER_FLAT;
+    trgl_uniforms uniforms{};
+    const double* varyings = nullptr;   // K doubles for `kind`, valid until rasterize() returns
+    std::uint32_t color = 0xffffffffu;  // FLAT / GOURAUD
+};
+
+struct IShader {
+    static TGAColor sample2D(const TGAImage& img, const vec2& uv) {
+        int x = std::min<int>(img.width() - 1, std::max<int>(0, int(uv.x * img.width())));
+        int y = std::min<int>(img.height() - 1, std::max<int>(0, int(uv.y * img.height())));
+        return img.get(x, y);
+    }
+    virtual vec4 vertex(int, int) { return vec4(); }
+    // Executed on the device; never called on the host.
+    virtual std::pair<bool, TGAColor> fragment(const vec3) const {
+        std::fprintf(stderr, "trgl: IShader::fragment() runs on the GPU; give the shader a describe()\n");
+        std::abort();
+    }
+    virtual bool describe(trgl_shader_desc&) const { return false; }
+    virtual ~IShader() = default;
+};
+
+typedef vec<4> Triangle[3];
+
+namespace trgl_shim {
+
+struct State {
+    trgl_ctx* ctx = nullptr;
+    int w = 0, h = 0, bpp = 0;
+    bool zbuffer_dirty_on_host = false;   // init_zbuffer()/host writes not yet on the device
+    bool have_batch = false;
+    int kind = 0;
+    trgl_uniforms uniforms{};
+    std::vector<double> clip, vary;
+    std::vector<std::uint32_t> colors;
+    mat<4, 4> viewport_at_batch;
+};
+inline State& state() { static State s; return s; }
+
+inline void die(const char* what, trgl_ctx* c) {
+    std::fprintf(stderr, "trgl: %s failed: %s\n", what, trgl_last_error(c));
+    std::abort();
+}
+#define TRGL_SHIM_CHK(call) do { if ((call) != TRGL_OK) ::trgl_shim::die(#call, ::trgl_shim::state().ctx); } while (0)
+
+inline int device_from_env() { const char* e = std::getenv("TRGL_DEVICE"); return e ? std::atoi(e) : 0; }
+
+// make sure a context matching the framebuffer exists and holds the host's current pixels / depths
+inline void bind(TGAImage& fb) {
+    State& s = state();
+    if (s.ctx && (s.w != fb.width() || s.h != fb.height() || s.bpp != fb.bytespp())) { trgl_destroy(s.ctx); s.ctx = nullptr; }
+    if (!s.ctx) {
+        if (trgl_create(device_from_env(), fb.width(), fb.height(), fb.bytespp(), &s.ctx) != TRGL_OK) die("trgl_create", nullptr);
+        s.w = fb.width(); s.h = fb.height(); s.bpp = fb.bytespp();
+        TRGL_SHIM_CHK(trgl_write_framebuffer(s.ctx, fb.buffer()));
+        s.zbuffer_dirty_on_host = true;
+    }
+    if (s.zbuffer_dirty_on_host) {
+        if (zbuffer.size() != std::size_t(s.w) * s.h) zbuffer.assign(std::size_t(s.w) * s.h, std::numeric_limits<double>::infinity());
+        TRGL_SHIM_CHK(trgl_write_zbuffer(s.ctx, zbuffer.data()));
+        s.zbuffer_dirty_on_host = false;
+    }
+}
+
+inline void submit_batch() {
+    State& s = state();
+    if (!s.have_batch) return;
+    double vp[16];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) vp[4 * r + c] = s.viewport_at_batch[r][c];
+    TRGL_SHIM_CHK(trgl_set_viewport(s.ctx, vp));
+    TRGL_SHIM_CHK(trgl_draw(s.ctx, s.kind, &s.uniforms, s.clip.data(), s.vary.empty() ? nullptr : s.vary.data(),
+                            s.colors.data(), s.clip.size() / 12, TRGL_MEM_HOST));
+    s.clip.clear(); s.vary.clear(); s.colors.clear();
+    s.have_batch = false;
+}
+
+inline int vary_count(int kind) {
+    return kind == TRGL_SHADER_GOURAUD ? TRGL_VARY_GOURAUD : (kind == TRGL_SHADER_PHONG || kind == TRGL_SHADER_EYE) ? TRGL_VARY_PHONG : 0;
+}
+inline bool same_matrix(const mat<4, 4>& a, const mat<4, 4>& b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
+
+}  // namespace trgl_shim
+
+// ---- our_gl.h:25-31 ------------------------------------------------------------------------------
+inline void lookat(const vec3 eye, const vec3 center, const vec3 up) {            // our_gl.cpp:25-41
+    vec3 z = normalized(eye - center), x = normalized(cross(up, z)), y = cross(z, x);
+    ModelView = mat<4, 4>::identity();
+    for (int i = 0; i < 3; ++i) { ModelView[0][i] = x[i]; ModelView[1][i] = y[i]; ModelView[2][i] = z[i]; }
+    ModelView[0][3] = -dot(x, eye); ModelView[1][3] = -dot(y, eye); ModelView[2][3] = -dot(z, eye);
+}
+inline void init_perspective(double fov_deg, double aspect, double znear, double zfar) {   // our_gl.cpp:44-56
+    double t = std::tan(fov_deg * M_PI / 180.0 / 2.0);
+    Perspective = mat<4, 4>::identity();
+    Perspective[0][0] = 1.0 / (aspect * t);
+    Perspective[1][1] = 1.0 / t;
+    Perspective[2][2] = (zfar + znear) / (znear - zfar);
+    Perspective[2][3] = (2.0 * zfar * znear) / (znear - zfar);
+    Perspective[3][2] = -1.0;
+    Perspective[3][3] = 0.0;
+}
+inline void init_viewport(int x, int y, int w, int h) {                           // our_gl.cpp:59-69
+    Viewport = mat<4, 4>::identity();
+    Viewport[0][0] = w / 2.0; Viewport[1][1] = h / 2.0;
+    Viewport[0][3] = x + w / 2.0; Viewport[1][3] = y + h / 2.0;
+    Viewport[2][2] = 1.0; Viewport[2][3] = 0.0;
+}
+inline void init_zbuffer(int width, int height) {                                 // our_gl.cpp:72-74
+    trgl_shim::State& s = trgl_shim::state();
+    if (s.ctx) { trgl_shim::submit_batch(); TRGL_SHIM_CHK(trgl_flush(s.ctx)); }
+    zbuffer.assign(std::size_t(width) * height, std::numeric_limits<double>::infinity());
+    s.zbuffer_dirty_on_host = true;
+}
+
+// Tell the shim the host changed `zbuffer` (main.cpp:730 restores a saved copy) or the framebuffer's pixels.
+inline void gl_zbuffer_modified() { trgl_shim::state().zbuffer_dirty_on_host = true; }
+inline void gl_framebuffer_modified(TGAImage& fb) {
+    trgl_shim::State& s = trgl_shim::state();
+    if (s.ctx) { trgl_shim::submit_batch(); TRGL_SHIM_CHK(trgl_write_framebuffer(s.ctx, fb.buffer())); }
+}
+
+// Model textures live on the device: TGAImage::buffer() layout, one slot per map (include/trgl.h).
+inline void gl_upload_texture(TGAImage& framebuffer, int slot, const TGAImage& img) {
+    trgl_shim::bind(framebuffer);
+    trgl_shim::submit_batch();
+    TRGL_SHIM_CHK(trgl_upload_texture(trgl_shim::state().ctx, slot, img.buffer(), img.width(), img.height(), img.bytespp()));
+}
+
+// ---- our_gl.h:58 ---------------------------------------------------------------------------------
+inline void rasterize(const Triangle& clip, const IShader& shader, TGAImage& framebuffer) {
+    using namespace trgl_shim;
+    State& s = state();
+    bind(framebuffer);
+    trgl_shader_desc d;
+    if (!shader.describe(d)) {
+        std::fprintf(stderr, "trgl: rasterize(): this IShader subclass has no device descriptor (describe()); "
+                             "the fragment stage runs on the GPU and there is no CPU fallback\n");
+        std::abort();
+    }
+    const int K = vary_count(d.kind);
+    if (s.have_batch && (s.kind != d.kind || std::memcmp(&s.uniforms, &d.uniforms, sizeof(trgl_uniforms)) != 0 ||
+                         !same_matrix(s.viewport_at_batch, Viewport)))
+        submit_batch();
+    if (!s.have_batch) { s.have_batch = true; s.kind = d.kind; s.uniforms = d.uniforms; s.viewport_at_batch = Viewport; }
+    for (int v = 0; v < 3; ++v) for (int c = 0; c < 4; ++c) s.clip.push_back(clip[v][c]);
+    for (int k = 0; k < K; ++k) s.vary.push_back(d.varyings[k]);
+    s.colors.push_back(d.color);
+    if (s.clip.size() >= std::size_t(12) << 20) submit_batch();      // bound host memory: 1 Mi triangles per batch
+}
+
+// Run everything submitted so far and bring framebuffer + zbuffer back to the host objects the reference's
+// callers read directly.
+inline void gl_flush(TGAImage& framebuffer) {
+    using namespace trgl_shim;
+    State& s = state();
+    bind(framebuffer);
+    submit_batch();
+    TRGL_SHIM_CHK(trgl_read_framebuffer(s.ctx, framebuffer.buffer()));
+    zbuffer.resize(std::size_t(s.w) * s.h);
+    TRGL_SHIM_CHK(trgl_read_zbuffer(s.ctx, zbuffer.data()));
+}
+
+inline void print_render_stats() {                                                // our_gl.cpp:204-210
+    trgl_shim::State& s = trgl_shim::state();
+    trgl_stats st{};
+    if (s.ctx) { trgl_shim::submit_batch(); TRGL_SHIM_CHK(trgl_get_stats(s.ctx, &st)); }
+    else { st.min_x = st.min_y = INT32_MAX; st.max_x = st.max_y = INT32_MIN; st.min_z = std::numeric_limits<double>::infinity(); st.max_z = -st.min_z; }
+    char line[256];
+    trgl_format_stats(&st, line, sizeof line);
+    std::fputs(line, stderr);
+}
+inline void gl_shutdown() { trgl_shim::State& s = trgl_shim::state(); if (s.ctx) { trgl_destroy(s.ctx); s.ctx = nullptr; } }

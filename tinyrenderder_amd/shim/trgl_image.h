@@ -1,0 +1,135 @@
+// trgl_image.h — TGAColor / TGAImage with the reference's interface (tgaimage.h:29-104) and the
+// byte-exact TGA file format of its writer (tgaimage.cpp:161-242): 18-byte header, no footer,
+// imagedescriptor 0x00 when vflip (the default), RLE packets formed exactly as the reference forms
+// them (its raw packets run up to AND INCLUDING the first pixel of the next repeated pair).
+// Host-only; this is SURVEY.md §8(f) row N3.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+struct TGAColor {
+    std::uint8_t bgra[4] = { 0, 0, 0, 255 };
+    std::uint8_t bytespp = 4;
+    TGAColor() = default;
+    TGAColor(std::uint8_t R, std::uint8_t G, std::uint8_t B, std::uint8_t A = 255) : bgra{ B, G, R, A }, bytespp(4) {}
+    TGAColor(std::uint8_t v) : bgra{ v, v, v, 255 }, bytespp(1) {}
+    TGAColor(const std::uint8_t* p, std::uint8_t bpp) : bgra{ 0, 0, 0, 0 }, bytespp(bpp) { for (int i = 0; i < bpp; ++i) bgra[i] = p[i]; }
+    std::uint8_t& operator[](int i) { return bgra[i]; }
+    const std::uint8_t& operator[](int i) const { return bgra[i]; }
+    TGAColor operator*(float k) const {
+        TGAColor r = *this;
+        if (k < 0.f) k = 0.f;
+        if (k > 1.f) k = 1.f;
+        for (int i = 0; i < 4; ++i) r.bgra[i] = std::uint8_t(bgra[i] * k);
+        return r;
+    }
+    std::uint32_t packed() const { return bgra[0] | (std::uint32_t(bgra[1]) << 8) | (std::uint32_t(bgra[2]) << 16) | (std::uint32_t(bgra[3]) << 24); }
+};
+
+class TGAImage {
+public:
+    enum Format { GRAYSCALE = 1, RGB = 3, RGBA = 4 };
+    TGAImage() = default;
+    TGAImage(int width, int height, int bytespp, TGAColor clear = TGAColor()) : w(width), h(height), bpp(std::uint8_t(bytespp)) {
+        data.resize(std::size_t(w) * h * bpp);
+        for (std::size_t i = 0; i < std::size_t(w) * h; ++i) for (int k = 0; k < bpp; ++k) data[i * bpp + k] = clear.bgra[k];
+    }
+    int width() const { return w; }
+    int height() const { return h; }
+    int bytespp() const { return bpp; }
+    std::uint8_t* buffer() { return data.empty() ? nullptr : data.data(); }
+    const std::uint8_t* buffer() const { return data.empty() ? nullptr : data.data(); }
+    TGAColor get(int x, int y) const {
+        if (data.empty() || x < 0 || y < 0 || x >= w || y >= h) return TGAColor();
+        return TGAColor(&data[(std::size_t(x) + std::size_t(y) * w) * bpp], bpp);
+    }
+    void set(int x, int y, const TGAColor& c) {
+        if (data.empty() || x < 0 || y < 0 || x >= w || y >= h) return;
+        std::memcpy(&data[(std::size_t(x) + std::size_t(y) * w) * bpp], c.bgra, bpp);
+    }
+    void flip_vertically() {
+        std::size_t line = std::size_t(w) * bpp;
+        std::vector<std::uint8_t> tmp(line);
+        for (int y = 0; y < h / 2; ++y) {
+            std::uint8_t* a = &data[y * line]; std::uint8_t* b = &data[(h - 1 - y) * line];
+            std::memcpy(tmp.data(), a, line); std::memcpy(a, b, line); std::memcpy(b, tmp.data(), line);
+        }
+    }
+    void flip_horizontally() {
+        for (int y = 0; y < h; ++y) for (int x = 0; x < w / 2; ++x) for (int k = 0; k < bpp; ++k)
+            std::swap(data[(std::size_t(x) + std::size_t(y) * w) * bpp + k], data[(std::size_t(w - 1 - x) + std::size_t(y) * w) * bpp + k]);
+    }
+
+    // The exact bytes TGAImage::write_tga_file(name, vflip, rle) puts on disk.
+    std::vector<std::uint8_t> encode_tga(bool vflip = true, bool rle = true) const {
+        std::vector<std::uint8_t> out(18, 0);
+        out[2] = bpp == 1 ? (rle ? 11 : 3) : (rle ? 10 : 2);
+        out[12] = std::uint8_t(w & 0xff); out[13] = std::uint8_t((w >> 8) & 0xff);
+        out[14] = std::uint8_t(h & 0xff); out[15] = std::uint8_t((h >> 8) & 0xff);
+        out[16] = std::uint8_t(bpp * 8);
+        out[17] = vflip ? 0x00 : 0x20;
+        if (!rle) { out.insert(out.end(), data.begin(), data.end()); return out; }
+        const int npix = w * h, maxrun = 128;
+        auto same = [&](int a, int b) { return std::memcmp(&data[std::size_t(a) * bpp], &data[std::size_t(b) * bpp], bpp) == 0; };
+        for (int cur = 0; cur < npix;) {
+            int run = 1;
+            while (cur + run < npix && run < maxrun && same(cur + run, cur)) ++run;
+            if (run > 1) {                                   // repeat packet
+                out.push_back(std::uint8_t(run - 1 + 128));
+                out.insert(out.end(), &data[std::size_t(cur) * bpp], &data[std::size_t(cur) * bpp] + bpp);
+            } else {                                         // literal packet: stops AFTER meeting an equal neighbour pair
+                while (cur + run < npix && run < maxrun && !same(cur + run, cur + run - 1)) ++run;
+                out.push_back(std::uint8_t(run - 1));
+                out.insert(out.end(), &data[std::size_t(cur) * bpp], &data[std::size_t(cur) * bpp] + std::size_t(run) * bpp);
+            }
+            cur += run;
+        }
+        return out;
+    }
+    bool write_tga_file(const std::string& filename, bool vflip = true, bool rle = true) const {
+        std::ofstream out(filename, std::ios::binary);
+        if (!out.is_open()) return false;
+        auto bytes = encode_tga(vflip, rle);
+        out.write(reinterpret_cast<const char*>(bytes.data()), std::streamsize(bytes.size()));
+        return bool(out);
+    }
+    bool read_tga_file(const std::string& filename) {
+        std::ifstream in(filename, std::ios::binary);
+        if (!in.is_open()) return false;
+        std::uint8_t hd[18];
+        in.read(reinterpret_cast<char*>(hd), 18);
+        if (!in.good()) return false;
+        w = hd[12] | (hd[13] << 8); h = hd[14] | (hd[15] << 8); bpp = hd[16] >> 3;
+        if (w <= 0 || h <= 0 || (bpp != 1 && bpp != 3 && bpp != 4)) return false;
+        data.assign(std::size_t(w) * h * bpp, 0);
+        in.seekg(hd[0], std::ios::cur);
+        if (hd[2] == 2 || hd[2] == 3) {
+            in.read(reinterpret_cast<char*>(data.data()), std::streamsize(data.size()));
+        } else if (hd[2] == 10 || hd[2] == 11) {
+            int npix = w * h, cur = 0;
+            std::uint8_t px[4];
+            while (cur < npix) {
+                int head = in.get();
+                if (head < 0) return false;
+                int count = head < 128 ? head + 1 : head - 127;
+                if (head >= 128) in.read(reinterpret_cast<char*>(px), bpp);
+                for (int i = 0; i < count; ++i) {
+                    if (head < 128) in.read(reinterpret_cast<char*>(px), bpp);
+                    if (cur >= npix) return false;
+                    std::memcpy(&data[std::size_t(cur++) * bpp], px, bpp);
+                }
+            }
+        } else return false;
+        if (!(hd[17] & 0x20)) flip_vertically();
+        if (hd[17] & 0x10) flip_horizontally();
+        return true;
+    }
+
+private:
+    int w = 0, h = 0;
+    std::uint8_t bpp = 0;
+    std::vector<std::uint8_t> data;
+};
