@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--triangles", type=int, default=10_000_000)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="triangles timed on the host CPU (0 = skip)")
+    ap.add_argument("--force-dist", action="store_true", help="run the RCCL strip-gather path even with one rank (rehearsal)")
     args = ap.parse_args()
 
     import torch
@@ -77,9 +78,12 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     W = H = args.size
     N = args.triangles
@@ -91,7 +95,7 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)          # order with torch / RCCL on one stream
     y0, y1 = shard.strip_rows(H, world, rank)
     full_fb = None
-    if world > 1:
+    if use_dist:
         ctx.set_strip(y0, y1)
         full_fb = torch.as_tensor(_DevBuf(ctx.framebuffer_ptr, W * H * 3), device="cuda")
 
@@ -99,11 +103,11 @@ def main():
         ctx.clear()
         ctx.draw(FLAT, dclip, colors=dcol, device=True)
         ctx.flush()
-        if world > 1:   # join the colour strips: every rank ends with the whole TGAImage buffer
+        if use_dist:   # join the colour strips: every rank ends with the whole TGAImage buffer
             shard.gather_strips(full_fb, W, H, 3, rank, world)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -117,7 +121,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -159,7 +163,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(clip, col, W, H, args.cpu_sample)
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

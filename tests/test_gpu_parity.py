@@ -172,3 +172,18 @@ def test_badly_scaled_triangles_take_the_literal_path():
     assert np.array_equal(z.view(np.uint64), o.z.view(np.uint64))
     assert np.array_equal(fb, o.fb)
     assert st == o.stats
+
+
+def test_bench_rccl_strip_gather_path_single_rank():
+    """bench.py's N>1 code path (strip context + in-place RCCL all-gather on the context's own framebuffer memory,
+    one stream shared with torch) rehearsed with a 1-rank process group: a 1-GPU box cannot host two RCCL ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1",
+                        "--triangles", "300000", "--size", "1024", "--cpu-sample", "0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0
