@@ -169,9 +169,10 @@ void* trgl_framebuffer_device_ptr(trgl_ctx* ctx);
 void* trgl_zbuffer_device_ptr(trgl_ctx* ctx);
 /* The hipStream_t all work of this context is enqueued on. */
 void* trgl_stream(trgl_ctx* ctx);
-/* Enqueue on the caller's hipStream_t instead (e.g. the stream a collective library orders against);
- * NULL returns to the context's own stream.  The caller keeps the stream alive.  Implies a sync. */
-int trgl_set_stream(trgl_ctx* ctx, void* hip_stream);
+/* Enqueue on the caller's hipStream_t instead (e.g. the stream a collective library orders against).  A NULL
+ * handle is the legacy default stream — a real stream, and what torch's current stream usually is — so returning
+ * to the context's own stream is use_own != 0.  The caller keeps its stream alive.  Implies a sync. */
+int trgl_set_stream(trgl_ctx* ctx, void* hip_stream, int use_own);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 

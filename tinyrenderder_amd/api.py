@@ -110,7 +110,7 @@ def load_library(path: str = LIB_PATH):
     L.trgl_format_stats.argtypes = [C.POINTER(Stats), C.c_char_p, C.c_size_t]
     for name in ("trgl_framebuffer_device_ptr", "trgl_zbuffer_device_ptr", "trgl_stream"):
         getattr(L, name).argtypes = [vp]; getattr(L, name).restype = C.c_void_p
-    L.trgl_set_stream.argtypes = [vp, C.c_void_p]
+    L.trgl_set_stream.argtypes = [vp, C.c_void_p, C.c_int]
     L.trgl_set_profiling.argtypes = [vp, C.c_int]
     L.trgl_get_phase_ms.argtypes = [vp, dp, u64p]
     L.trgl_reset_phase_ms.argtypes = [vp]
@@ -286,9 +286,10 @@ class Context:
     def stream(self) -> int:
         return self.L.trgl_stream(self.h)
 
-    def set_stream(self, hip_stream):
-        """Enqueue on the caller's hipStream_t (int pointer, e.g. torch.cuda.current_stream().cuda_stream)."""
-        self._chk(self.L.trgl_set_stream(self.h, hip_stream))
+    def set_stream(self, hip_stream, use_own: bool = False):
+        """Enqueue on the caller's hipStream_t (int handle, e.g. torch.cuda.current_stream().cuda_stream; 0 is the
+        legacy default stream).  use_own=True returns to the context's own stream."""
+        self._chk(self.L.trgl_set_stream(self.h, hip_stream or None, 1 if use_own else 0))
 
     # ---- measurement ----
     def set_profiling(self, on: bool):
