@@ -209,10 +209,14 @@ __device__ __forceinline__ double div_by_uz(double a, double uz, double ruz) {
     return __builtin_fma(e1, ruz, q1);
 }
 
-// our_gl.cpp:147-199 for one triangle on one tile: 8x8 pixel blocks, one pixel per lane.
-template <bool FLAT_ONLY>
+// our_gl.cpp:147-199 for one triangle on one tile.  A wave step covers a region of NX x NY 8x8 pixel blocks: every
+// lane carries NX*NY independent pixels.  The kernel is bound by the latency of dependent fp64 operations (3 waves
+// per SIMD, LDS-limited), so independent chains per lane are what fills the pipe; blocks of the region that lie
+// outside the bbox or get no coverage cost little.
+template <bool FLAT_ONLY, int NX, int NY>
 __device__ __forceinline__ void raster_triangle(const TriConst& T, TileState& S, const DrawDesc* __restrict__ draws,
                                                 const DevTexture* __restrict__ tex, DevStats* __restrict__ stats) {
+    constexpr int NB = NX * NY;
     const int lane = S.lane;
     const bool well_scaled = T.ruz != 0.0;          // wave-uniform
     const double uz = T.uz, ruz = T.ruz;
@@ -222,67 +226,84 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, TileState& S,
         asm volatile("" :: "v"(T.ax), "v"(T.ay), "v"(T.s0x), "v"(T.s0y), "v"(T.s1x), "v"(T.s1y), "v"(T.uz), "v"(T.ruz), "v"(T.z0), "v"(T.z1), "v"(T.z2), "v"(T.color), "s"(x0 + x1 + y0 + y1));
         return;
     }
-    for (int by = y0; by <= y1; by += 8) {
-        for (int bx = x0; bx <= x1; bx += 8) {
-            const int x = bx + (lane & 7), y = by + (lane >> 3);
-            const bool act = (x <= x1) && (y <= y1);
-            // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
-            const double pxc = (double)x + 0.5, pyc = (double)y + 0.5;        // :149
-            const double s0z = T.ax - pxc, s1z = T.ay - pyc;
-            const double ux = T.s0y * s1z - s0z * T.s1y;                      // geometry.h:145
-            const double uy = s0z * T.s1x - T.s0x * s1z;                      // geometry.h:146
-            const double us = ux + uy;
-            double b0, b1, b2;
-            bool cov;
-            if (well_scaled) {
-                // u.z < 0 and nothing can over/underflow, so the signs of the quotients are known
-                // without dividing: u.y/u.z < 0 <=> u.y > 0, u.x/u.z < 0 <=> u.x > 0, and
-                // 1 - RN(us/u.z) < 0 <=> RN(us/u.z) > 1 <=> us < u.z  ("exactness").
-                cov = act && !(us < uz) && !(uy > 0.0) && !(ux > 0.0);        // :152
-                if (__ballot(cov) == 0) continue;        // whole 8x8 block outside: no division at all
-                if (S.ablate == 2) { asm volatile("" :: "v"(us), "v"(ux), "v"(uy)); continue; }   // diagnostic: coverage signs only
-                b0 = 1.0 - div_by_uz(us, uz, ruz);
-                b1 = div_by_uz(uy, uz, ruz);
-                b2 = div_by_uz(ux, uz, ruz);
-            } else {
-                b0 = 1.0 - us / uz;                                           // :85, as written
-                b1 = uy / uz;
-                b2 = ux / uz;
-                cov = act && !(b0 < 0 || b1 < 0 || b2 < 0);                   // :152
-            }
-            const double z = b0 * T.z0 + b1 * T.z1 + b2 * T.z2;               // :156-158
-            cov = cov && __builtin_isfinite(z);                               // :160
-            if (__ballot(cov) == 0) continue;
-            if (S.ablate == 3) { asm volatile("" :: "v"(z)); continue; }      // diagnostic: everything but the LDS z-test / write
-            const int li = lds_index(x, y);
-            const double zold = S.zt[li];
-            if (cov && (z < zold)) {                                          // :165
-                uint32_t color;
-                if (FLAT_ONLY) {
-                    color = T.color;
+    for (int by = y0; by <= y1; by += 8 * NY) {
+        for (int bx = x0; bx <= x1; bx += 8 * NX) {
+            int x[NB], y[NB];
+            double ux[NB], uy[NB], us[NB], b0[NB], b1[NB], b2[NB], z[NB];
+            bool cov[NB];
+            unsigned long long any[NB];
+            // ---- barycentric() numerators, our_gl.cpp:77-80 (s0.xy, s1.xy and u.z hoisted into the record)
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                x[k] = bx + 8 * (k % NX) + (lane & 7);
+                y[k] = by + 8 * (k / NX) + (lane >> 3);
+                const bool act = (x[k] <= x1) && (y[k] <= y1);
+                const double pxc = (double)x[k] + 0.5, pyc = (double)y[k] + 0.5;      // :149
+                const double s0z = T.ax - pxc, s1z = T.ay - pyc;
+                ux[k] = T.s0y * s1z - s0z * T.s1y;                                    // geometry.h:145
+                uy[k] = s0z * T.s1x - T.s0x * s1z;                                    // geometry.h:146
+                us[k] = ux[k] + uy[k];
+                if (well_scaled) {
+                    // u.z < 0 and nothing can over/underflow, so the signs of the quotients are known without
+                    // dividing: u.y/u.z < 0 <=> u.y > 0, u.x/u.z < 0 <=> u.x > 0, and
+                    // 1 - RN(us/u.z) < 0 <=> RN(us/u.z) > 1 <=> us < u.z  ("exactness").
+                    cov[k] = act && !(us[k] < uz) && !(uy[k] > 0.0) && !(ux[k] > 0.0);    // :152
                 } else {
-                    const DrawDesc& d = draws[T.dl >> 24];
-                    if (d.kind == TRGL_SHADER_FLAT) {
+                    b0[k] = 1.0 - us[k] / uz;                                         // :85, as written
+                    b1[k] = uy[k] / uz;
+                    b2[k] = ux[k] / uz;
+                    cov[k] = act && !(b0[k] < 0 || b1[k] < 0 || b2[k] < 0);           // :152
+                }
+                any[k] = __ballot(cov[k]);
+            }
+            if (S.ablate == 2) { for (int k = 0; k < NB; ++k) asm volatile("" :: "v"(us[k]), "v"(ux[k]), "v"(uy[k])); continue; }
+            // ---- quotients and depth, only for 8x8 blocks with coverage (wave-uniform skips) -------------
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if (any[k] == 0) continue;
+                if (well_scaled) {
+                    b0[k] = 1.0 - div_by_uz(us[k], uz, ruz);
+                    b1[k] = div_by_uz(uy[k], uz, ruz);
+                    b2[k] = div_by_uz(ux[k], uz, ruz);
+                }
+                z[k] = b0[k] * T.z0 + b1[k] * T.z1 + b2[k] * T.z2;                    // :156-158
+                cov[k] = cov[k] && __builtin_isfinite(z[k]);                          // :160
+            }
+            if (S.ablate == 3) { for (int k = 0; k < NB; ++k) asm volatile("" :: "v"(z[k])); continue; }
+            // ---- z-test and write, our_gl.cpp:162-198 (pixels of one triangle are distinct: any order) ----
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if (any[k] == 0) continue;
+                const int li = lds_index(x[k], y[k]);
+                const double zold = S.zt[li];
+                if (cov[k] && (z[k] < zold)) {                                        // :165
+                    uint32_t color;
+                    if (FLAT_ONLY) {
                         color = T.color;
                     } else {
-                        const uint32_t local = T.dl & 0xffffffu;
-                        double pc[3];
-                        const double denom = b0 * T.iw0 + b1 * T.iw1 + b2 * T.iw2;            // :172-174
-                        if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }      // :177-185
-                        else { pc[0] = (b0 * T.iw0) / denom; pc[1] = (b1 * T.iw1) / denom; pc[2] = (b2 * T.iw2) / denom; }
-                        const double* vary = d.vary + (size_t)local * d.K;
-                        if (d.kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(d.colors ? d.colors[local] : 0xffffffffu, vary, pc);
-                        else if (d.kind == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
-                        else color = frag_eye(d.u, tex, vary, pc).bgra;
+                        const DrawDesc& d = draws[T.dl >> 24];
+                        if (d.kind == TRGL_SHADER_FLAT) {
+                            color = T.color;
+                        } else {
+                            const uint32_t local = T.dl & 0xffffffu;
+                            double pc[3];
+                            const double denom = b0[k] * T.iw0 + b1[k] * T.iw1 + b2[k] * T.iw2;       // :172-174
+                            if (fabs(denom) < 1e-15) { pc[0] = b0[k]; pc[1] = b1[k]; pc[2] = b2[k]; } // :177-185
+                            else { pc[0] = (b0[k] * T.iw0) / denom; pc[1] = (b1[k] * T.iw1) / denom; pc[2] = (b2[k] * T.iw2) / denom; }
+                            const double* vary = d.vary + (size_t)local * d.K;
+                            if (d.kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(d.colors ? d.colors[local] : 0xffffffffu, vary, pc);
+                            else if (d.kind == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
+                            else color = frag_eye(d.u, tex, vary, pc).bgra;
+                        }
                     }
-                }
-                S.zt[li] = z;                                                 // :191
-                S.ct[li] = color;                                             // :192
-                ++S.frags;                                                    // :194
-                S.zmin = dmin(S.zmin, z); S.zmax = dmax(S.zmax, z);           // :197-198
-                if (z == 0.0 && !S.zero_locked) {       // rare: remember which signed zero came first
-                    unsigned long long order = ((unsigned long long)T.tri << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
-                    atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
+                    S.zt[li] = z[k];                                                  // :191
+                    S.ct[li] = color;                                                 // :192
+                    ++S.frags;                                                        // :194
+                    S.zmin = dmin(S.zmin, z[k]); S.zmax = dmax(S.zmax, z[k]);         // :197-198
+                    if (z[k] == 0.0 && !S.zero_locked) {  // rare: remember which signed zero came first
+                        unsigned long long order = ((unsigned long long)T.tri << 32) | ((unsigned long long)x[k] << 16) | (unsigned long long)y[k];
+                        atomicMin(__builtin_signbit(z[k]) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
+                    }
                 }
             }
         }
@@ -347,7 +368,7 @@ __device__ __forceinline__ TriConst tri_from_uniform(const RecU& c, uint32_t tri
     return T;
 }
 
-template <bool FLAT_ONLY, int FETCH>
+template <bool FLAT_ONLY, int FETCH, int NX, int NY>
 __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
                                                 const uint32_t* __restrict__ tile_start,
@@ -421,7 +442,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
             }
             for (uint32_t j = 0; j < nbatch; ++j) {
                 const TriConst T = tri_from_lane<FLAT_ONLY>(cur, j);
-                raster_triangle<FLAT_ONLY>(T, S, draws, tex, stats);
+                raster_triangle<FLAT_ONLY, NX, NY>(T, S, draws, tex, stats);
             }
             cur = nxt;
         }
@@ -458,7 +479,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                     r[(k + 2) % 3] = load_rec_uniform<FLAT_ONLY>(recs, tid[(k + 2) % 3]);
                 }
                 const TriConst T = tri_from_uniform<FLAT_ONLY>(r[k], tid[k]);
-                raster_triangle<FLAT_ONLY>(T, S, draws, tex, stats);
+                raster_triangle<FLAT_ONLY, NX, NY>(T, S, draws, tex, stats);
             }
         }
     }
@@ -599,14 +620,20 @@ void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const T
     int rows = fp.strip_ty1 - fp.strip_ty0;
     if (rows <= 0) return;
     dim3 grid((fp.tiles_x + TRGL_WAVES_PER_BLOCK - 1) / TRGL_WAVES_PER_BLOCK, rows);
-    if (flat_only && variant == 0)
-        hipLaunchKernelGGL((k_raster<true, 0>), grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats);
-    else if (flat_only)
-        hipLaunchKernelGGL((k_raster<true, 1>), grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats);
-    else if (variant == 0)
-        hipLaunchKernelGGL((k_raster<false, 0>), grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats);
-    else
-        hipLaunchKernelGGL((k_raster<false, 1>), grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats);
+#define TRGL_LAUNCH_RASTER(F, V, NX, NY) hipLaunchKernelGGL((k_raster<F, V, NX, NY>), grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats)
+    // variant: bit 0 = record fetch (0 readlane, 1 uniform loads); bits 4.. = region shape (0: 1x1, 1: 2x1, 2: 2x2 blocks)
+    const int fetch = variant & 1, shape = (variant >> 4) & 3;
+    if (flat_only) {
+        if (fetch) TRGL_LAUNCH_RASTER(true, 1, 1, 1);
+        else if (shape == 0) TRGL_LAUNCH_RASTER(true, 0, 1, 1);
+        else if (shape == 1) TRGL_LAUNCH_RASTER(true, 0, 2, 1);
+        else TRGL_LAUNCH_RASTER(true, 0, 2, 2);
+    } else {
+        if (fetch) TRGL_LAUNCH_RASTER(false, 1, 1, 1);
+        else if (shape == 0) TRGL_LAUNCH_RASTER(false, 0, 1, 1);
+        else TRGL_LAUNCH_RASTER(false, 0, 2, 1);
+    }
+#undef TRGL_LAUNCH_RASTER
     hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(1), 0, s, stats);
 }
 

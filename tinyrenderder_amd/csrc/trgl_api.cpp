@@ -137,7 +137,7 @@ int trgl_create(int device, int width, int height, int bpp, trgl_ctx** out) {
     c->tiles_x = (width + TRGL_TILE - 1) / TRGL_TILE;
     c->tiles_y = (height + TRGL_TILE - 1) / TRGL_TILE;
     c->strip_y0 = 0; c->strip_y1 = height;
-    if (const char* e = std::getenv("TRGL_RASTER_VARIANT")) c->raster_variant = std::atoi(e) ? 1 : 0;
+    if (const char* e = std::getenv("TRGL_RASTER_VARIANT")) c->raster_variant = (int)std::strtol(e, nullptr, 0);
     std::memset(c->tex_host, 0, sizeof(c->tex_host));
     size_t npx = (size_t)width * height, ntiles = (size_t)c->tiles_x * c->tiles_y;
 #define CRE(expr) do { hipError_t e2 = (expr); if (e2 != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e2); trgl_destroy(c); return TRGL_E_HIP; } } while (0)
