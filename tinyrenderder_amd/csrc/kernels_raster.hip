@@ -185,17 +185,19 @@ __device__ __forceinline__ int lds_index(int x, int y) {
     return ((y & (TRGL_TILE - 1)) << TRGL_TILE_LOG2) + ((x & (TRGL_TILE - 1)) ^ ((y & 3) << 3));
 }
 
-// Per-triangle constants of the pixel loop (wave-uniform), however they were fetched.
-struct TriConst {
-    double ax, ay, s0x, s0y, s1x, s1y, uz, ruz, z0, z1, z2, iw0, iw1, iw2;
-    uint32_t bb0, bb1, color, dl, tri;
-};
-// Per-wave tile state.
-struct TileState {
-    int lane, px0, xa1, ya0, ya1, ablate;
-    double* zt; uint32_t* ct;
-    uint32_t frags; double zmin, zmax; bool zero_locked;
-};
+// A wave's batch of triangle records: lane i holds record i (8 x 16 B) and its triangle id.
+struct RecQ { uint4 q[8]; uint32_t tri; };
+__device__ __forceinline__ RecQ load_rec(const TriRec* __restrict__ recs, uint32_t tri, bool valid) {
+    RecQ r; r.tri = tri;
+    const uint4* p = reinterpret_cast<const uint4*>(recs + tri);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.q[k] = valid ? p[k] : make_uint4(0, 0, 0, 0);
+    return r;
+}
+__device__ __forceinline__ uint32_t bcast_u(uint32_t v, uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)j); }
+__device__ __forceinline__ double bcast_d(uint32_t lo, uint32_t hi, uint32_t j) {
+    return __hiloint2double(__builtin_amdgcn_readlane((int)hi, (int)j), __builtin_amdgcn_readlane((int)lo, (int)j));
+}
 
 // a / uz, correctly rounded, for the per-triangle constant uz with ruz = RN(1/uz) (Markstein):
 // q0 = RN(a*ruz) is within 2 ulp of a/uz; one FMA residual step makes q1 faithful (error < 1 ulp),
@@ -209,166 +211,7 @@ __device__ __forceinline__ double div_by_uz(double a, double uz, double ruz) {
     return __builtin_fma(e1, ruz, q1);
 }
 
-// our_gl.cpp:147-199 for one triangle on one tile.  A wave step covers a region of NX x NY 8x8 pixel blocks: every
-// lane carries NX*NY independent pixels.  The kernel is bound by the latency of dependent fp64 operations (3 waves
-// per SIMD, LDS-limited), so independent chains per lane are what fills the pipe; blocks of the region that lie
-// outside the bbox or get no coverage cost little.
-template <bool FLAT_ONLY, int NX, int NY>
-__device__ __forceinline__ void raster_triangle(const TriConst& T, TileState& S, const DrawDesc* __restrict__ draws,
-                                                const DevTexture* __restrict__ tex, DevStats* __restrict__ stats) {
-    constexpr int NB = NX * NY;
-    const int lane = S.lane;
-    const bool well_scaled = T.ruz != 0.0;          // wave-uniform
-    const double uz = T.uz, ruz = T.ruz;
-    const int x0 = max((int)(T.bb0 & 0xffff), S.px0), x1 = min((int)(T.bb1 & 0xffff), S.xa1);
-    const int y0 = max((int)(T.bb0 >> 16), S.ya0), y1 = min((int)(T.bb1 >> 16), S.ya1);
-    if (S.ablate == 1) {   // diagnostic: per-triangle overhead only (keep the constants alive)
-        asm volatile("" :: "v"(T.ax), "v"(T.ay), "v"(T.s0x), "v"(T.s0y), "v"(T.s1x), "v"(T.s1y), "v"(T.uz), "v"(T.ruz), "v"(T.z0), "v"(T.z1), "v"(T.z2), "v"(T.color), "s"(x0 + x1 + y0 + y1));
-        return;
-    }
-    for (int by = y0; by <= y1; by += 8 * NY) {
-        for (int bx = x0; bx <= x1; bx += 8 * NX) {
-            int x[NB], y[NB];
-            double ux[NB], uy[NB], us[NB], b0[NB], b1[NB], b2[NB], z[NB];
-            bool cov[NB];
-            unsigned long long any[NB];
-            // ---- barycentric() numerators, our_gl.cpp:77-80 (s0.xy, s1.xy and u.z hoisted into the record)
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                x[k] = bx + 8 * (k % NX) + (lane & 7);
-                y[k] = by + 8 * (k / NX) + (lane >> 3);
-                const bool act = (x[k] <= x1) && (y[k] <= y1);
-                const double pxc = (double)x[k] + 0.5, pyc = (double)y[k] + 0.5;      // :149
-                const double s0z = T.ax - pxc, s1z = T.ay - pyc;
-                ux[k] = T.s0y * s1z - s0z * T.s1y;                                    // geometry.h:145
-                uy[k] = s0z * T.s1x - T.s0x * s1z;                                    // geometry.h:146
-                us[k] = ux[k] + uy[k];
-                if (well_scaled) {
-                    // u.z < 0 and nothing can over/underflow, so the signs of the quotients are known without
-                    // dividing: u.y/u.z < 0 <=> u.y > 0, u.x/u.z < 0 <=> u.x > 0, and
-                    // 1 - RN(us/u.z) < 0 <=> RN(us/u.z) > 1 <=> us < u.z  ("exactness").
-                    cov[k] = act && !(us[k] < uz) && !(uy[k] > 0.0) && !(ux[k] > 0.0);    // :152
-                } else {
-                    b0[k] = 1.0 - us[k] / uz;                                         // :85, as written
-                    b1[k] = uy[k] / uz;
-                    b2[k] = ux[k] / uz;
-                    cov[k] = act && !(b0[k] < 0 || b1[k] < 0 || b2[k] < 0);           // :152
-                }
-                any[k] = __ballot(cov[k]);
-            }
-            if (S.ablate == 2) { for (int k = 0; k < NB; ++k) asm volatile("" :: "v"(us[k]), "v"(ux[k]), "v"(uy[k])); continue; }
-            // ---- quotients and depth, only for 8x8 blocks with coverage (wave-uniform skips) -------------
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                if (any[k] == 0) continue;
-                if (well_scaled) {
-                    b0[k] = 1.0 - div_by_uz(us[k], uz, ruz);
-                    b1[k] = div_by_uz(uy[k], uz, ruz);
-                    b2[k] = div_by_uz(ux[k], uz, ruz);
-                }
-                z[k] = b0[k] * T.z0 + b1[k] * T.z1 + b2[k] * T.z2;                    // :156-158
-                cov[k] = cov[k] && __builtin_isfinite(z[k]);                          // :160
-            }
-            if (S.ablate == 3) { for (int k = 0; k < NB; ++k) asm volatile("" :: "v"(z[k])); continue; }
-            // ---- z-test and write, our_gl.cpp:162-198 (pixels of one triangle are distinct: any order) ----
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                if (any[k] == 0) continue;
-                const int li = lds_index(x[k], y[k]);
-                const double zold = S.zt[li];
-                if (cov[k] && (z[k] < zold)) {                                        // :165
-                    uint32_t color;
-                    if (FLAT_ONLY) {
-                        color = T.color;
-                    } else {
-                        const DrawDesc& d = draws[T.dl >> 24];
-                        if (d.kind == TRGL_SHADER_FLAT) {
-                            color = T.color;
-                        } else {
-                            const uint32_t local = T.dl & 0xffffffu;
-                            double pc[3];
-                            const double denom = b0[k] * T.iw0 + b1[k] * T.iw1 + b2[k] * T.iw2;       // :172-174
-                            if (fabs(denom) < 1e-15) { pc[0] = b0[k]; pc[1] = b1[k]; pc[2] = b2[k]; } // :177-185
-                            else { pc[0] = (b0[k] * T.iw0) / denom; pc[1] = (b1[k] * T.iw1) / denom; pc[2] = (b2[k] * T.iw2) / denom; }
-                            const double* vary = d.vary + (size_t)local * d.K;
-                            if (d.kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(d.colors ? d.colors[local] : 0xffffffffu, vary, pc);
-                            else if (d.kind == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
-                            else color = frag_eye(d.u, tex, vary, pc).bgra;
-                        }
-                    }
-                    S.zt[li] = z[k];                                                  // :191
-                    S.ct[li] = color;                                                 // :192
-                    ++S.frags;                                                        // :194
-                    S.zmin = dmin(S.zmin, z[k]); S.zmax = dmax(S.zmax, z[k]);         // :197-198
-                    if (z[k] == 0.0 && !S.zero_locked) {  // rare: remember which signed zero came first
-                        unsigned long long order = ((unsigned long long)T.tri << 32) | ((unsigned long long)x[k] << 16) | (unsigned long long)y[k];
-                        atomicMin(__builtin_signbit(z[k]) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
-                    }
-                }
-            }
-        }
-    }
-}
-
-// ---- record fetch, variant 0: 64 records per batch, one per lane, broadcast with v_readlane ----------
-struct RecQ { uint4 q[8]; uint32_t tri; };
-__device__ __forceinline__ RecQ load_rec(const TriRec* __restrict__ recs, uint32_t tri, bool valid) {
-    RecQ r; r.tri = tri;
-    const uint4* p = reinterpret_cast<const uint4*>(recs + tri);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) r.q[k] = valid ? p[k] : make_uint4(0, 0, 0, 0);
-    return r;
-}
-__device__ __forceinline__ uint32_t bcast_u(uint32_t v, uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)j); }
-__device__ __forceinline__ double bcast_d(uint32_t lo, uint32_t hi, uint32_t j) {
-    return __hiloint2double(__builtin_amdgcn_readlane((int)hi, (int)j), __builtin_amdgcn_readlane((int)lo, (int)j));
-}
 template <bool FLAT_ONLY>
-__device__ __forceinline__ TriConst tri_from_lane(const RecQ& c, uint32_t j) {
-    TriConst T;
-    T.ax = bcast_d(c.q[0].x, c.q[0].y, j); T.ay = bcast_d(c.q[0].z, c.q[0].w, j);
-    T.s0x = bcast_d(c.q[1].x, c.q[1].y, j); T.s0y = bcast_d(c.q[1].z, c.q[1].w, j);
-    T.s1x = bcast_d(c.q[2].x, c.q[2].y, j); T.s1y = bcast_d(c.q[2].z, c.q[2].w, j);
-    T.uz = bcast_d(c.q[3].x, c.q[3].y, j); T.ruz = bcast_d(c.q[3].z, c.q[3].w, j);
-    T.z0 = bcast_d(c.q[4].x, c.q[4].y, j); T.z1 = bcast_d(c.q[4].z, c.q[4].w, j); T.z2 = bcast_d(c.q[5].x, c.q[5].y, j);
-    if (!FLAT_ONLY) {
-        T.iw0 = bcast_d(c.q[5].z, c.q[5].w, j); T.iw1 = bcast_d(c.q[6].x, c.q[6].y, j); T.iw2 = bcast_d(c.q[6].z, c.q[6].w, j);
-        T.dl = bcast_u(c.q[7].w, j);
-    } else { T.iw0 = T.iw1 = T.iw2 = 0.0; T.dl = 0; }
-    T.bb0 = bcast_u(c.q[7].x, j); T.bb1 = bcast_u(c.q[7].y, j); T.color = bcast_u(c.q[7].z, j);
-    T.tri = bcast_u(c.tri, j);
-    return T;
-}
-
-// ---- record fetch, variant 1: every lane loads the SAME record (wave-uniform address): the constants
-// arrive in VGPRs through the vector memory pipe, no VALU broadcast; records are requested two
-// triangles ahead (three register sets rotate through a 3x unrolled loop) ---------------------------------
-struct RecU { uint4 q[8]; };
-template <bool FLAT_ONLY>
-__device__ __forceinline__ RecU load_rec_uniform(const TriRec* __restrict__ recs, uint32_t tri) {
-    RecU r;
-    const uint4* p = reinterpret_cast<const uint4*>(recs + tri);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) if (FLAT_ONLY ? (k != 6) : true) r.q[k] = p[k]; else r.q[k] = make_uint4(0, 0, 0, 0);
-    return r;
-}
-__device__ __forceinline__ double mk_d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
-template <bool FLAT_ONLY>
-__device__ __forceinline__ TriConst tri_from_uniform(const RecU& c, uint32_t tri) {
-    TriConst T;
-    T.ax = mk_d(c.q[0].x, c.q[0].y); T.ay = mk_d(c.q[0].z, c.q[0].w);
-    T.s0x = mk_d(c.q[1].x, c.q[1].y); T.s0y = mk_d(c.q[1].z, c.q[1].w);
-    T.s1x = mk_d(c.q[2].x, c.q[2].y); T.s1y = mk_d(c.q[2].z, c.q[2].w);
-    T.uz = mk_d(c.q[3].x, c.q[3].y); T.ruz = mk_d(c.q[3].z, c.q[3].w);
-    T.z0 = mk_d(c.q[4].x, c.q[4].y); T.z1 = mk_d(c.q[4].z, c.q[4].w); T.z2 = mk_d(c.q[5].x, c.q[5].y);
-    T.iw0 = mk_d(c.q[5].z, c.q[5].w); T.iw1 = mk_d(c.q[6].x, c.q[6].y); T.iw2 = mk_d(c.q[6].z, c.q[6].w);
-    T.bb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.q[7].x); T.bb1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.q[7].y);
-    T.color = c.q[7].z; T.dl = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.q[7].w);
-    T.tri = tri;
-    return T;
-}
-
-template <bool FLAT_ONLY, int FETCH, int NX, int NY>
 __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
                                                 const uint32_t* __restrict__ tile_start,
@@ -389,7 +232,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
     const int xa1 = min(px0 + TRGL_TILE - 1, fp.W - 1);
     const int ya0 = max(py0, fp.strip_y0), ya1 = min(min(py0 + TRGL_TILE - 1, fp.H - 1), fp.strip_y1 - 1);
 
-    const uint32_t beg = tile_start[t], end = tile_end[t];
+    uint32_t beg = tile_start[t], end = tile_end[t];
     if (!fp.init_from_clear && beg == end) return;       // nothing to composite onto this tile
 
     double* zt = s_z[w];
@@ -413,78 +256,113 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
         }
     }
 
-    TileState S;
-    S.ablate = fp.ablate;
-    S.lane = lane; S.px0 = px0; S.xa1 = xa1; S.ya0 = ya0; S.ya1 = ya1; S.zt = zt; S.ct = ct;
-    S.frags = 0; S.zmin = __builtin_inf(); S.zmax = -__builtin_inf();
-    S.zero_locked = stats->zero_locked != 0;
+    uint32_t frags = 0;
+    double zmin = __builtin_inf(), zmax = -__builtin_inf();
+    const bool zero_locked = stats->zero_locked != 0;
 
     // ---- the tile's triangles, in submission order --------------------------------------------
-    if (FETCH == 0) {
-        // 64 records at a time: lane i holds the 128-B record of the batch's i-th triangle in registers
-        // (the next batch is already in flight while this one is rasterized); per-triangle constants are
-        // broadcast with v_readlane into SGPRs.
-        RecQ cur;
-        if (beg < end) {                 // an empty tile must not touch vals/recs at all (they may be null)
-            uint32_t p = beg + lane;
-            cur = load_rec(recs, vals[p < end ? p : end - 1], true);
-        } else {
-            cur.tri = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) cur.q[k] = make_uint4(0, 0, 0, 0);
-        }
-        for (uint32_t bs = beg; bs < end; bs += 64) {
-            const uint32_t nbatch = min(64u, end - bs);
-            RecQ nxt = cur;
-            if (bs + 64 < end) {
-                uint32_t p = bs + 64 + lane;
-                nxt = load_rec(recs, vals[p < end ? p : end - 1], true);
-            }
-            for (uint32_t j = 0; j < nbatch; ++j) {
-                const TriConst T = tri_from_lane<FLAT_ONLY>(cur, j);
-                raster_triangle<FLAT_ONLY, NX, NY>(T, S, draws, tex, stats);
-            }
-            cur = nxt;
-        }
+    // 64 records at a time: lane i holds the 128-B record of the batch's i-th triangle in registers
+    // (the next batch is already in flight while this one is rasterized), and the per-triangle
+    // constants are broadcast with v_readlane into SGPRs.  One HBM round trip per 64 triangles
+    // instead of two dependent ones per triangle.
+    RecQ cur;
+    if (beg < end) {                     // an empty tile must not touch vals/recs at all
+        uint32_t p = beg + lane;
+        cur = load_rec(recs, vals[p < end ? p : end - 1], true);
     } else {
-        // triangle ids 64 at a time (lane i = id i, next 64 in flight); records by wave-uniform loads two
-        // triangles ahead.  Slot k of the rotation holds the record of list position p with (p - beg) % 3 == k.
-        uint32_t ids_cur = 0, ids_nxt = 0;
-        if (beg < end) { uint32_t p = beg + lane; ids_cur = vals[p < end ? p : end - 1]; }
-        if (beg + 64 < end) { uint32_t p = beg + 64 + lane; ids_nxt = vals[p < end ? p : end - 1]; }
-        // id of list position p, for p within the current or the next batch of 64
-        auto id_at = [&](uint32_t p, uint32_t batch_start) -> uint32_t {
-            const uint32_t o = p - batch_start;
-            return o < 64 ? bcast_u(ids_cur, o) : bcast_u(ids_nxt, o - 64);
-        };
-        RecU r[3];
-        uint32_t tid[3] = { 0, 0, 0 };
-        uint32_t bstart = beg;
-        if (beg < end) { tid[0] = id_at(beg, bstart); r[0] = load_rec_uniform<FLAT_ONLY>(recs, tid[0]); }
-        if (beg + 1 < end) { tid[1] = id_at(beg + 1, bstart); r[1] = load_rec_uniform<FLAT_ONLY>(recs, tid[1]); }
-        for (uint32_t p0 = beg; p0 < end; p0 += 3) {
+        cur.tri = 0;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const uint32_t p = p0 + k;
-                if (p >= end) break;
-                // request the record two positions ahead into the slot that was consumed last step
-                const uint32_t pa = p + 2;
-                if (pa < end) {
-                    if (pa - bstart >= 128) {      // ids of position pa live beyond ids_nxt: advance the id window
-                        bstart += 64; ids_cur = ids_nxt;
-                        uint32_t q = bstart + 64 + lane;
-                        ids_nxt = vals[q < end ? q : end - 1];
+        for (int k = 0; k < 8; ++k) cur.q[k] = make_uint4(0, 0, 0, 0);
+    }
+    for (uint32_t bs = beg; bs < end; bs += 64) {
+        const uint32_t nbatch = min(64u, end - bs);
+        RecQ nxt = cur;
+        if (bs + 64 < end) {
+            uint32_t p = bs + 64 + lane;
+            nxt = load_rec(recs, vals[p < end ? p : end - 1], true);
+        }
+        for (uint32_t j = 0; j < nbatch; ++j) {
+            const double r_ax = bcast_d(cur.q[0].x, cur.q[0].y, j), r_ay = bcast_d(cur.q[0].z, cur.q[0].w, j);
+            const double r_s0x = bcast_d(cur.q[1].x, cur.q[1].y, j), r_s0y = bcast_d(cur.q[1].z, cur.q[1].w, j);
+            const double r_s1x = bcast_d(cur.q[2].x, cur.q[2].y, j), r_s1y = bcast_d(cur.q[2].z, cur.q[2].w, j);
+            const double uz = bcast_d(cur.q[3].x, cur.q[3].y, j), ruz = bcast_d(cur.q[3].z, cur.q[3].w, j);
+            const double r_z0 = bcast_d(cur.q[4].x, cur.q[4].y, j), r_z1 = bcast_d(cur.q[4].z, cur.q[4].w, j),
+                         r_z2 = bcast_d(cur.q[5].x, cur.q[5].y, j);
+            const uint32_t bb0 = bcast_u(cur.q[7].x, j), bb1 = bcast_u(cur.q[7].y, j);
+            const uint32_t r_color = bcast_u(cur.q[7].z, j);
+            const uint32_t tri = bcast_u(cur.tri, j);
+            const bool well_scaled = ruz != 0.0;          // wave-uniform
+            const int x0 = max((int)(bb0 & 0xffff), px0), x1 = min((int)(bb1 & 0xffff), xa1);
+            const int y0 = max((int)(bb0 >> 16), ya0), y1 = min((int)(bb1 >> 16), ya1);
+            for (int by = y0; by <= y1; by += 8) {
+                for (int bx = x0; bx <= x1; bx += 8) {
+                    const int x = bx + (lane & 7), y = by + (lane >> 3);
+                    const bool act = (x <= x1) && (y <= y1);
+                    // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
+                    const double pxc = (double)x + 0.5, pyc = (double)y + 0.5;        // :149
+                    const double s0z = r_ax - pxc, s1z = r_ay - pyc;
+                    const double ux = r_s0y * s1z - s0z * r_s1y;                      // geometry.h:145
+                    const double uy = s0z * r_s1x - r_s0x * s1z;                      // geometry.h:146
+                    const double us = ux + uy;
+                    double b0, b1, b2;
+                    bool cov;
+                    if (well_scaled) {
+                        // u.z < 0 and nothing can over/underflow, so the signs of the quotients are known
+                        // without dividing: u.y/u.z < 0 <=> u.y > 0, u.x/u.z < 0 <=> u.x > 0, and
+                        // 1 - RN(us/u.z) < 0 <=> RN(us/u.z) > 1 <=> us < u.z  ("exactness").
+                        cov = act && !(us < uz) && !(uy > 0.0) && !(ux > 0.0);        // :152
+                        if (__ballot(cov) == 0) continue;        // whole 8x8 block outside: no division at all
+                        b0 = 1.0 - div_by_uz(us, uz, ruz);
+                        b1 = div_by_uz(uy, uz, ruz);
+                        b2 = div_by_uz(ux, uz, ruz);
+                    } else {
+                        b0 = 1.0 - us / uz;                                           // :85, as written
+                        b1 = uy / uz;
+                        b2 = ux / uz;
+                        cov = act && !(b0 < 0 || b1 < 0 || b2 < 0);                   // :152
                     }
-                    tid[(k + 2) % 3] = id_at(pa, bstart);
-                    r[(k + 2) % 3] = load_rec_uniform<FLAT_ONLY>(recs, tid[(k + 2) % 3]);
+                    const double z = b0 * r_z0 + b1 * r_z1 + b2 * r_z2;               // :156-158
+                    cov = cov && __builtin_isfinite(z);                               // :160
+                    if (__ballot(cov) == 0) continue;
+                    const int li = lds_index(x, y);
+                    const double zold = zt[li];
+                    if (cov && (z < zold)) {                                          // :165
+                        uint32_t color;
+                        if (FLAT_ONLY) {
+                            color = r_color;
+                        } else {
+                            const uint32_t dl = bcast_u(cur.q[7].w, j);
+                            const DrawDesc& d = draws[dl >> 24];
+                            if (d.kind == TRGL_SHADER_FLAT) {
+                                color = r_color;
+                            } else {
+                                const uint32_t local = dl & 0xffffffu;
+                                const double iw0 = bcast_d(cur.q[5].z, cur.q[5].w, j), iw1 = bcast_d(cur.q[6].x, cur.q[6].y, j),
+                                             iw2 = bcast_d(cur.q[6].z, cur.q[6].w, j);
+                                double pc[3];
+                                const double denom = b0 * iw0 + b1 * iw1 + b2 * iw2;              // :172-174
+                                if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }  // :177-185
+                                else { pc[0] = (b0 * iw0) / denom; pc[1] = (b1 * iw1) / denom; pc[2] = (b2 * iw2) / denom; }
+                                const double* vary = d.vary + (size_t)local * d.K;
+                                if (d.kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(d.colors ? d.colors[local] : 0xffffffffu, vary, pc);
+                                else if (d.kind == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
+                                else color = frag_eye(d.u, tex, vary, pc).bgra;
+                            }
+                        }
+                        zt[li] = z;                                                   // :191
+                        ct[li] = color;                                               // :192
+                        ++frags;                                                      // :194
+                        zmin = dmin(zmin, z); zmax = dmax(zmax, z);                   // :197-198
+                        if (z == 0.0 && !zero_locked) {       // rare: remember which signed zero came first
+                            unsigned long long order = ((unsigned long long)tri << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
+                            atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
+                        }
+                    }
                 }
-                const TriConst T = tri_from_uniform<FLAT_ONLY>(r[k], tid[k]);
-                raster_triangle<FLAT_ONLY, NX, NY>(T, S, draws, tex, stats);
             }
         }
+        cur = nxt;
     }
-    uint32_t frags = S.frags;
-    const double zmin = S.zmin, zmax = S.zmax;
 
     // ---- tile out: row-contiguous stores --------------------------------------------------------
     const bool full_x = (px0 + TRGL_TILE - 1) <= xa1;
@@ -616,24 +494,14 @@ void launch_selftest_division(hipStream_t s, unsigned long long n_per_thread, un
 
 void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const TriRec* recs, const uint32_t* vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
-                   const DevTexture* tex, DevStats* stats, int variant) {
+                   const DevTexture* tex, DevStats* stats) {
     int rows = fp.strip_ty1 - fp.strip_ty0;
     if (rows <= 0) return;
     dim3 grid((fp.tiles_x + TRGL_WAVES_PER_BLOCK - 1) / TRGL_WAVES_PER_BLOCK, rows);
-#define TRGL_LAUNCH_RASTER(F, V, NX, NY) hipLaunchKernelGGL((k_raster<F, V, NX, NY>), grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats)
-    // variant: bit 0 = record fetch (0 readlane, 1 uniform loads); bits 4.. = region shape (0: 1x1, 1: 2x1, 2: 2x2 blocks)
-    const int fetch = variant & 1, shape = (variant >> 4) & 3;
-    if (flat_only) {
-        if (fetch) TRGL_LAUNCH_RASTER(true, 1, 1, 1);
-        else if (shape == 0) TRGL_LAUNCH_RASTER(true, 0, 1, 1);
-        else if (shape == 1) TRGL_LAUNCH_RASTER(true, 0, 2, 1);
-        else TRGL_LAUNCH_RASTER(true, 0, 2, 2);
-    } else {
-        if (fetch) TRGL_LAUNCH_RASTER(false, 1, 1, 1);
-        else if (shape == 0) TRGL_LAUNCH_RASTER(false, 0, 1, 1);
-        else TRGL_LAUNCH_RASTER(false, 0, 2, 1);
-    }
-#undef TRGL_LAUNCH_RASTER
+    if (flat_only)
+        hipLaunchKernelGGL(k_raster<true>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats);
+    else
+        hipLaunchKernelGGL(k_raster<false>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats);
     hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(1), 0, s, stats);
 }
 

@@ -23,7 +23,7 @@ void launch_bounds(hipStream_t s, const uint32_t* keys, uint32_t P, uint32_t* ti
 
 void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const TriRec* recs, const uint32_t* vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
-                   const DevTexture* tex, DevStats* stats, int variant);
+                   const DevTexture* tex, DevStats* stats);
 
 void launch_selftest_division(hipStream_t s, unsigned long long n_per_thread, unsigned long long seed,
                               unsigned long long* mismatches);

@@ -65,8 +65,6 @@ struct trgl_ctx {
     double phase_ms[TRGL_NUM_PHASES] = { 0, 0, 0, 0 };
     uint64_t flushes_timed = 0;
 
-    int raster_variant = 0;             // record fetch strategy of k_raster (TRGL_RASTER_VARIANT=0|1, for A/B runs)
-
     std::string err;
 };
 
@@ -137,7 +135,6 @@ int trgl_create(int device, int width, int height, int bpp, trgl_ctx** out) {
     c->tiles_x = (width + TRGL_TILE - 1) / TRGL_TILE;
     c->tiles_y = (height + TRGL_TILE - 1) / TRGL_TILE;
     c->strip_y0 = 0; c->strip_y1 = height;
-    if (const char* e = std::getenv("TRGL_RASTER_VARIANT")) c->raster_variant = (int)std::strtol(e, nullptr, 0);
     std::memset(c->tex_host, 0, sizeof(c->tex_host));
     size_t npx = (size_t)width * height, ntiles = (size_t)c->tiles_x * c->tiles_y;
 #define CRE(expr) do { hipError_t e2 = (expr); if (e2 != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e2); trgl_destroy(c); return TRGL_E_HIP; } } while (0)
@@ -328,7 +325,6 @@ int trgl_flush(trgl_ctx* c) {
     fp.init_from_clear = c->clear_pending ? 1 : 0;
     fp.clear_color = c->clear_color; fp.clear_z = c->clear_z;
     std::memcpy(fp.vp, c->vp, sizeof(fp.vp));
-    if (const char* e = std::getenv("TRGL_RASTER_ABLATE")) fp.ablate = std::atoi(e);   // diagnostic runs only
 
     bool flat_only = true;
     for (auto& d : c->draws) if (d.kind != TRGL_SHADER_FLAT) flat_only = false;
@@ -391,8 +387,7 @@ int trgl_flush(trgl_ctx* c) {
     // valid addresses anyway
     const TriRec* recs_arg = c->recs ? c->recs : reinterpret_cast<const TriRec*>(c->tile_start);
     const uint32_t* vals_arg = (P && c->vals[cur]) ? c->vals[cur] : c->tile_start;
-    launch_raster(s, fp, flat_only, recs_arg, vals_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev,
-                  c->raster_variant);
+    launch_raster(s, fp, flat_only, recs_arg, vals_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev);
     if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[3], s)); c->events_pending = true; }
     HIPCHK(c, hipGetLastError());
 

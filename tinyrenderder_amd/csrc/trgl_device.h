@@ -77,5 +77,4 @@ struct FrameParams {
     uint32_t clear_color;             // packed BGRA
     double   clear_z;
     double   vp[8];                   // rows 0 and 1 of the Viewport matrix (our_gl.cpp:117-121)
-    int32_t  ablate;                  // diagnostic builds only (TRGL_RASTER_ABLATE): 0 = normal
 };
