@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="triangles timed on the host CPU (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL strip-gather path even with one rank (rehearsal)")
+    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3"],
+                    help="c4 (default, the metric's config): 10 M random flat triangles; c2/c3: PHONG head stand-in at 2048/4096")
     args = ap.parse_args()
 
     import torch
@@ -85,13 +87,29 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    from tinyrenderder_amd.api import PHONG, make_uniforms
     W = H = args.size
     N = args.triangles
-    clip, col = scenes.random_triangles(N, W, H)                    # same seed on every rank
+    kind, uniforms, dvary, K, textures = FLAT, None, None, 0, {}
+    if args.workload == "c4":
+        clip, col = scenes.random_triangles(N, W, H)                    # same seed on every rank
+        dcol = torch.from_numpy(col.view(np.int32)).cuda()
+        wl_name = f"configs[3]: {N} synthetic random triangles, {W}x{H} RGB + fp64 z, flat shader"
+    else:   # secondary workloads (not the headline metric): BASELINE configs[1]/[2], PHONG on the head stand-in
+        W = H = 2048 if args.workload == "c2" else 4096
+        hd = scenes.head_standin(7, W, H)
+        clip, col, dcol, N, kind, K = hd["clip"], None, None, hd["clip"].shape[0], PHONG, 24
+        d_, n_, s_ = scenes.procedural_textures(1024)
+        textures = {0: d_} if args.workload == "c2" else {0: d_, 1: n_, 2: s_}
+        slots = (0, -1, -1) if args.workload == "c2" else (0, 1, 2)
+        uniforms = make_uniforms(hd["model_view"], hd["key"], hd["fill"], hd["rim"], 1.0, *slots)
+        dvary = torch.from_numpy(hd["varyings"]).cuda()
+        wl_name = f"configs[{1 if args.workload == 'c2' else 2}]: {N}-triangle head stand-in, {W}x{H}, PHONG, maps {sorted(textures)}"
     dclip = torch.from_numpy(clip).cuda()
-    dcol = torch.from_numpy(col.view(np.int32)).cuda()
 
     ctx = Context(W, H, 3, device=local_rank)
+    for slot, t in textures.items():
+        ctx.upload_texture(slot, t)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)          # order with torch / RCCL on one stream
     y0, y1 = shard.strip_rows(H, world, rank)
     full_fb = None
@@ -101,7 +119,7 @@ def main():
 
     def step():
         ctx.clear()
-        ctx.draw(FLAT, dclip, colors=dcol, device=True)
+        ctx.draw(kind, dclip, varyings=dvary, colors=dcol, uniforms=uniforms, device=True)
         ctx.flush()
         if use_dist:   # join the colour strips: every rank ends with the whole TGAImage buffer
             shard.gather_strips(full_fb, W, H, 3, rank, world)
@@ -134,7 +152,7 @@ def main():
         tri_per_s = N * args.steps / elapsed
         # dominant kernel = the tile raster; algorithmic bytes per launch: every pixel's colour and z
         # leave the chip once (W*H*11 B) and every triangle's clip-space vertices are consumed once (N*96 B).
-        algo_bytes = (W * H * 11 + N * 96) / world if world > 1 else (W * H * 11 + N * 96)
+        algo_bytes = (W * H * 11 + N * (96 + 8 * K)) / world
         raster_ms = phase_ms[PHASE_RASTER] / max(nfl, 1)
         achieved = algo_bytes / (raster_ms * 1e-3) / 1e9
         traffic = None
@@ -148,18 +166,18 @@ def main():
             "value": tri_per_s, "unit": "triangles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[3]: {N} synthetic random triangles, {W}x{H} RGB + fp64 z, flat shader",
+            "config": {"workload": wl_name,
                        "width": W, "height": H, "triangles": N, "tile": 32,
                        "parallelism": f"screen strips x{world}" + (" + RCCL all-gather of colour strips" if world > 1 else "")},
             "mpixels_per_s": W * H * args.steps / elapsed / 1e6,
             "tri_tile_pairs": info["pairs"],
             "phase_ms": {"setup": phase_ms[PHASE_SETUP] / max(nfl, 1), "bin": phase_ms[PHASE_BIN] / max(nfl, 1),
                          "raster": raster_ms, "flush_total": phase_ms[PHASE_TOTAL] / max(nfl, 1)},
-            "roofline": {"bound": "hbm", "kernel": "k_raster<flat>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_raster<flat>" if kind == FLAT else "k_raster<any shader>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": raster_ms},
         }
-        if world == 1 and args.cpu_sample > 0:
+        if world == 1 and args.cpu_sample > 0 and args.workload == "c4":
             out["cpu_baseline"] = cpu_baseline(clip, col, W, H, args.cpu_sample)
         print(json.dumps(out))
     ctx.close()

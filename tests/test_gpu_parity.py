@@ -187,3 +187,30 @@ def test_bench_rccl_strip_gather_path_single_rank():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("cfg", ["c2_2048_phong_diffuse", "c3_4096_phong_diffuse_normal_spec"])
+def test_baseline_phong_configs_full_size(cfg):
+    """BASELINE configs[1] and [2] at full resolution: PHONG on the 327 680-triangle head stand-in (african_head.obj
+    is absent from the reference tree) with 1024x1024 procedural maps, against the CPU oracle: z bit-identical,
+    colour byte-identical (PHONG's pow exponent is always 1.0, so no tolerance is needed), stats identical."""
+    from tinyrenderder_amd.api import PHONG, make_uniforms
+    size = 2048 if cfg.startswith("c2") else 4096
+    hd = scenes.head_standin(7, size, size)
+    d, n, s = scenes.procedural_textures(1024)
+    slots = (0, -1, -1) if cfg.startswith("c2") else (0, 1, 2)
+    tex = {0: d} if cfg.startswith("c2") else {0: d, 1: n, 2: s}
+    args = (hd["model_view"], hd["key"], hd["fill"], hd["rim"], 1.0) + slots
+    with Context(size, size, 3) as ctx:
+        for k, t in tex.items():
+            ctx.upload_texture(k, t)
+        ctx.draw(PHONG, hd["clip"], hd["varyings"], uniforms=make_uniforms(*args))
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    o = orc.Oracle(size, size, 3)
+    for k, t in tex.items():
+        o.upload_texture(k, t)
+    o.draw(orc.PHONG, hd["clip"], hd["varyings"], uniforms=orc.make_uniforms(*args))
+    assert np.array_equal(z.view(np.uint64), o.z.view(np.uint64))
+    assert np.array_equal(fb, o.fb)
+    assert st == o.stats
+    assert st[1] > 100_000          # the head covers a good part of the screen
