@@ -279,64 +279,116 @@ __global__ __launch_bounds__(256) void k_expand(uint32_t n, int tiles_x, const u
 }
 
 // ---------------------------------------------------------------------------------------------
-// stable LSD radix pass on `bits` key bits at `shift`.  Each WAVE owns a contiguous chunk of
-// RADIX_CHUNK pairs and walks it in order, 64 pairs a step; ranks inside a step come from ballots,
-// so equal keys keep their input order (= triangle submission order).
-// hist layout: [digit][worker] so one exclusive scan yields every worker's base per digit.
+// stable LSD radix pass on `bits` key bits at `shift`.  A 256-thread block owns RADIX_CHUNK consecutive
+// pairs; wave w owns the w-th quarter and walks it in order, 64 pairs a step, ranking equal digits
+// with ballots, so equal keys keep their input order (= triangle submission order).  The chunk is
+// then reordered by digit in LDS and written out linearly, so global stores are contiguous runs
+// (RADIX_CHUNK / 2^bits pairs per digit on average) instead of 64 scattered 4-byte elements per
+// instruction.  hist layout: [digit][block] so one exclusive scan yields every block's base per digit.
 // ---------------------------------------------------------------------------------------------
-constexpr int RADIX_CHUNK = 2048;
+constexpr int RADIX_CHUNK = 4096;
+constexpr int RADIX_WAVE_CHUNK = RADIX_CHUNK / 4;
+constexpr int RADIX_ROUNDS = RADIX_WAVE_CHUNK / 64;      // 16
 constexpr int RADIX_MAX_BITS = 8;
 
 __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, uint32_t P, int shift, int bits,
-                                                    uint32_t nworkers, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t s_cnt[4][1 << RADIX_MAX_BITS];
-    int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t worker = blockIdx.x * 4 + w;
-    uint32_t nb = 1u << bits, mask = nb - 1;
-    for (uint32_t b = lane; b < nb; b += 64) s_cnt[w][b] = 0;
-    __builtin_amdgcn_wave_barrier();
-    if (worker < nworkers) {
-        uint64_t beg = (uint64_t)worker * RADIX_CHUNK;
-        uint64_t end = beg + RADIX_CHUNK; if (end > P) end = P;
-        for (uint64_t p = beg + lane; p < end; p += 64) atomicAdd(&s_cnt[w][(keys[p] >> shift) & mask], 1u);
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t b = lane; b < nb; b += 64) hist[(size_t)b * nworkers + worker] = s_cnt[w][b];
-    }
+                                                    uint32_t nblocks, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_cnt[1 << RADIX_MAX_BITS];
+    const uint32_t nb = 1u << bits, mask = nb - 1;
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) s_cnt[b] = 0;
+    __syncthreads();
+    const uint64_t beg = (uint64_t)blockIdx.x * RADIX_CHUNK;
+    uint64_t end = beg + RADIX_CHUNK; if (end > P) end = P;
+    for (uint64_t p = beg + threadIdx.x; p < end; p += 256) atomicAdd(&s_cnt[(keys[p] >> shift) & mask], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) hist[(size_t)b * nblocks + blockIdx.x] = s_cnt[b];
 }
 
 __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                       uint32_t P, int shift, int bits, uint32_t nworkers,
+                                                       uint32_t P, int shift, int bits, uint32_t nblocks,
                                                        const uint32_t* __restrict__ base,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-    __shared__ uint32_t s_pos[4][1 << RADIX_MAX_BITS];
-    int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t worker = blockIdx.x * 4 + w;
-    if (worker >= nworkers) return;
-    uint32_t nb = 1u << bits, mask = nb - 1;
-    for (uint32_t b = lane; b < nb; b += 64) s_pos[w][b] = base[(size_t)b * nworkers + worker];
-    __builtin_amdgcn_wave_barrier();
-    uint64_t beg = (uint64_t)worker * RADIX_CHUNK;
-    uint64_t end = beg + RADIX_CHUNK; if (end > P) end = P;
-    unsigned long long lt = (1ull << lane) - 1ull;
-    for (uint64_t p0 = beg; p0 < end; p0 += 64) {
-        uint64_t p = p0 + lane;
-        bool act = p < end;
-        uint32_t k = act ? keys_in[p] : 0, v = act ? vals_in[p] : 0;
-        uint32_t dgt = (k >> shift) & mask;
+    __shared__ uint32_t s_cnt[4][1 << RADIX_MAX_BITS];     // per wave: running count, then (after phase 2) local start
+    __shared__ uint32_t s_start[1 << RADIX_MAX_BITS];      // first local position of each digit in the chunk
+    __shared__ uint32_t s_gbase[1 << RADIX_MAX_BITS];      // global position of the chunk's first pair of each digit
+    __shared__ uint32_t s_key[RADIX_CHUNK], s_val[RADIX_CHUNK];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t nb = 1u << bits, mask = nb - 1;
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) {
+        s_cnt[0][b] = 0; s_cnt[1][b] = 0; s_cnt[2][b] = 0; s_cnt[3][b] = 0;
+        s_gbase[b] = base[(size_t)b * nblocks + blockIdx.x];
+    }
+    __syncthreads();
+    const uint64_t cbeg = (uint64_t)blockIdx.x * RADIX_CHUNK;
+    uint64_t cend = cbeg + RADIX_CHUNK; if (cend > P) cend = P;
+    const uint32_t n_chunk = (uint32_t)(cend - cbeg);
+    const uint64_t wbeg = cbeg + (uint64_t)w * RADIX_WAVE_CHUNK;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    // ---- phase 1: stable rank of every pair among the equal digits of its wave's quarter ------------
+    uint32_t k[RADIX_ROUNDS], v[RADIX_ROUNDS], rk[RADIX_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < RADIX_ROUNDS; ++r) {
+        const uint64_t p = wbeg + (uint64_t)r * 64 + lane;
+        const bool act = p < cend;
+        k[r] = act ? keys_in[p] : 0; v[r] = act ? vals_in[p] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < RADIX_ROUNDS; ++r) {
+        const bool act = wbeg + (uint64_t)r * 64 + lane < cend;
+        const uint32_t dgt = (k[r] >> shift) & mask;
         unsigned long long same = __ballot(act);
         for (int b = 0; b < bits; ++b) {
-            unsigned long long bal = __ballot((dgt >> b) & 1u);
+            const unsigned long long bal = __ballot((dgt >> b) & 1u);
             same &= ((dgt >> b) & 1u) ? bal : ~bal;
         }
-        uint32_t rank = __popcll(same & lt);
-        uint32_t cur = act ? s_pos[w][dgt] : 0;
+        const uint32_t cur = act ? s_cnt[w][dgt] : 0;
         __builtin_amdgcn_wave_barrier();
-        if (act) {
-            uint32_t dst = cur + rank;
-            keys_out[dst] = k; vals_out[dst] = v;
-            if (rank == 0) s_pos[w][dgt] = cur + (uint32_t)__popcll(same);
+        const uint32_t r_in = __popcll(same & lt);
+        rk[r] = cur + r_in;
+        if (act && r_in == 0) s_cnt[w][dgt] = cur + (uint32_t)__popcll(same);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---- phase 2: local layout: digits ascending, inside a digit waves ascending ------------------------
+    if (w == 0) {
+        // exclusive scan over digits of the chunk totals (nb <= 256: up to 4 digits per lane)
+        uint32_t tot[4], run = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t d = lane * 4 + q;
+            tot[q] = d < nb ? s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d] : 0;
+            run += tot[q];
         }
-        __builtin_amdgcn_wave_barrier();
+        uint32_t inc = run;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        uint32_t ex = inc - run;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const uint32_t d = lane * 4 + q; if (d < nb) s_start[d] = ex; ex += tot[q]; }
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < nb; d += 256) {
+        uint32_t run = s_start[d];
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { const uint32_t c = s_cnt[ww][d]; s_cnt[ww][d] = run; run += c; }
+    }
+    __syncthreads();
+    // ---- phase 3: reorder in LDS ------------------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < RADIX_ROUNDS; ++r) {
+        if (wbeg + (uint64_t)r * 64 + lane < cend) {
+            const uint32_t dgt = (k[r] >> shift) & mask;
+            const uint32_t lp = s_cnt[w][dgt] + rk[r];
+            s_key[lp] = k[r]; s_val[lp] = v[r];
+        }
+    }
+    __syncthreads();
+    // ---- phase 4: linear read-out, contiguous global runs per digit ------------------------------------------
+    for (uint32_t i = threadIdx.x; i < n_chunk; i += 256) {
+        const uint32_t key = s_key[i];
+        const uint32_t dgt = (key >> shift) & mask;
+        const uint32_t dst = s_gbase[dgt] + (i - s_start[dgt]);
+        keys_out[dst] = key; vals_out[dst] = s_val[i];
     }
 }
 
@@ -378,16 +430,15 @@ void launch_expand(hipStream_t s, uint32_t n, int tiles_x, const uint32_t* cnt, 
     hipLaunchKernelGGL(k_expand, dim3((n + 255) / 256), dim3(256), 0, s, n, tiles_x, cnt, off, tilebox, keys, vals);
 }
 
-uint32_t radix_num_workers(uint32_t P) { return (P + RADIX_CHUNK - 1) / RADIX_CHUNK; }
+uint32_t radix_num_workers(uint32_t P) { return (P + RADIX_CHUNK - 1) / RADIX_CHUNK; }   // = blocks of a pass
 
 void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
                        uint32_t* vals_out, uint32_t P, int shift, int bits, uint32_t* hist, uint32_t* scan_tmp) {
     if (!P) return;
-    uint32_t nw = radix_num_workers(P);
-    uint32_t nblk = (nw + 3) / 4;
-    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(256), 0, s, keys_in, P, shift, bits, nw, hist);
-    launch_exclusive_scan(s, hist, hist, (uint64_t)nw << bits, scan_tmp, nullptr);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(256), 0, s, keys_in, vals_in, P, shift, bits, nw, hist,
+    uint32_t nblk = radix_num_workers(P);
+    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(256), 0, s, keys_in, P, shift, bits, nblk, hist);
+    launch_exclusive_scan(s, hist, hist, (uint64_t)nblk << bits, scan_tmp, nullptr);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(256), 0, s, keys_in, vals_in, P, shift, bits, nblk, hist,
                        keys_out, vals_out);
 }
 
