@@ -211,6 +211,94 @@ __device__ __forceinline__ double div_by_uz(double a, double uz, double ruz) {
     return __builtin_fma(e1, ruz, q1);
 }
 
+// Per-triangle constants of the pixel loop (wave-uniform: they live in SGPRs).
+struct TriConst {
+    double ax, ay, s0x, s0y, s1x, s1y, uz, ruz, z0, z1, z2, iw0, iw1, iw2;
+    uint32_t bb0, bb1, color, dl, tri;
+};
+// Per-wave tile state.
+struct TileState {
+    int lane, px0, xa1, ya0, ya1;
+    double* zt; uint32_t* ct;
+    uint32_t frags; double zmin, zmax; bool zero_locked;
+};
+
+// our_gl.cpp:147-199 for one triangle on one tile: 8x8 pixel blocks, one pixel per lane.
+// WELL_SCALED (see k_setup) selects the division-free coverage test and the FMA division by u.z; everything
+// after the coverage test sits under `if (cov)`, so a block with no covered pixel costs two scalar instructions.
+template <bool FLAT_ONLY, bool WELL_SCALED>
+__device__ __forceinline__ void raster_triangle(const TriConst& T, TileState& S, const DrawDesc* __restrict__ draws,
+                                                const DevTexture* __restrict__ tex, DevStats* __restrict__ stats) {
+    const int lane = S.lane;
+    const double uz = T.uz, ruz = T.ruz;
+    const int x0 = max((int)(T.bb0 & 0xffff), S.px0), x1 = min((int)(T.bb1 & 0xffff), S.xa1);
+    const int y0 = max((int)(T.bb0 >> 16), S.ya0), y1 = min((int)(T.bb1 >> 16), S.ya1);
+    for (int by = y0; by <= y1; by += 8) {
+        for (int bx = x0; bx <= x1; bx += 8) {
+            const int x = bx + (lane & 7), y = by + (lane >> 3);
+            const bool act = (x <= x1) && (y <= y1);
+            // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
+            const double pxc = (double)x + 0.5, pyc = (double)y + 0.5;        // :149
+            const double s0z = T.ax - pxc, s1z = T.ay - pyc;
+            const double ux = T.s0y * s1z - s0z * T.s1y;                      // geometry.h:145
+            const double uy = s0z * T.s1x - T.s0x * s1z;                      // geometry.h:146
+            const double us = ux + uy;
+            double b0, b1, b2;
+            bool cov;
+            if (WELL_SCALED) {
+                // u.z < 0 and nothing can over/underflow, so the signs of the quotients are known
+                // without dividing: u.y/u.z < 0 <=> u.y > 0, u.x/u.z < 0 <=> u.x > 0, and
+                // 1 - RN(us/u.z) < 0 <=> RN(us/u.z) > 1 <=> us < u.z  ("exactness").
+                cov = act && !(us < uz) && !(uy > 0.0) && !(ux > 0.0);        // :152
+            } else {
+                b0 = 1.0 - us / uz;                                           // :85, as written
+                b1 = uy / uz;
+                b2 = ux / uz;
+                cov = act && !(b0 < 0 || b1 < 0 || b2 < 0);                   // :152
+            }
+            if (cov) {
+                if (WELL_SCALED) {
+                    b0 = 1.0 - div_by_uz(us, uz, ruz);
+                    b1 = div_by_uz(uy, uz, ruz);
+                    b2 = div_by_uz(ux, uz, ruz);
+                }
+                const double z = b0 * T.z0 + b1 * T.z1 + b2 * T.z2;           // :156-158
+                const int li = lds_index(x, y);
+                const double zold = S.zt[li];
+                if (__builtin_isfinite(z) && (z < zold)) {                    // :160, :165
+                    uint32_t color;
+                    if (FLAT_ONLY) {
+                        color = T.color;
+                    } else {
+                        const DrawDesc& d = draws[T.dl >> 24];
+                        if (d.kind == TRGL_SHADER_FLAT) {
+                            color = T.color;
+                        } else {
+                            const uint32_t local = T.dl & 0xffffffu;
+                            double pc[3];
+                            const double denom = b0 * T.iw0 + b1 * T.iw1 + b2 * T.iw2;            // :172-174
+                            if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }      // :177-185
+                            else { pc[0] = (b0 * T.iw0) / denom; pc[1] = (b1 * T.iw1) / denom; pc[2] = (b2 * T.iw2) / denom; }
+                            const double* vary = d.vary + (size_t)local * d.K;
+                            if (d.kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(d.colors ? d.colors[local] : 0xffffffffu, vary, pc);
+                            else if (d.kind == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
+                            else color = frag_eye(d.u, tex, vary, pc).bgra;
+                        }
+                    }
+                    S.zt[li] = z;                                             // :191
+                    S.ct[li] = color;                                         // :192
+                    ++S.frags;                                                // :194
+                    S.zmin = dmin(S.zmin, z); S.zmax = dmax(S.zmax, z);       // :197-198
+                    if (z == 0.0 && !S.zero_locked) {       // rare: remember which signed zero came first
+                        unsigned long long order = ((unsigned long long)T.tri << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
+                        atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <bool FLAT_ONLY>
 __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
@@ -256,9 +344,10 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
         }
     }
 
-    uint32_t frags = 0;
-    double zmin = __builtin_inf(), zmax = -__builtin_inf();
-    const bool zero_locked = stats->zero_locked != 0;
+    TileState S;
+    S.lane = lane; S.px0 = px0; S.xa1 = xa1; S.ya0 = ya0; S.ya1 = ya1; S.zt = zt; S.ct = ct;
+    S.frags = 0; S.zmin = __builtin_inf(); S.zmax = -__builtin_inf();
+    S.zero_locked = stats->zero_locked != 0;
 
     // ---- the tile's triangles, in submission order --------------------------------------------
     // 64 records at a time: lane i holds the 128-B record of the batch's i-th triangle in registers
@@ -282,87 +371,27 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
             nxt = load_rec(recs, vals[p < end ? p : end - 1], true);
         }
         for (uint32_t j = 0; j < nbatch; ++j) {
-            const double r_ax = bcast_d(cur.q[0].x, cur.q[0].y, j), r_ay = bcast_d(cur.q[0].z, cur.q[0].w, j);
-            const double r_s0x = bcast_d(cur.q[1].x, cur.q[1].y, j), r_s0y = bcast_d(cur.q[1].z, cur.q[1].w, j);
-            const double r_s1x = bcast_d(cur.q[2].x, cur.q[2].y, j), r_s1y = bcast_d(cur.q[2].z, cur.q[2].w, j);
-            const double uz = bcast_d(cur.q[3].x, cur.q[3].y, j), ruz = bcast_d(cur.q[3].z, cur.q[3].w, j);
-            const double r_z0 = bcast_d(cur.q[4].x, cur.q[4].y, j), r_z1 = bcast_d(cur.q[4].z, cur.q[4].w, j),
-                         r_z2 = bcast_d(cur.q[5].x, cur.q[5].y, j);
-            const uint32_t bb0 = bcast_u(cur.q[7].x, j), bb1 = bcast_u(cur.q[7].y, j);
-            const uint32_t r_color = bcast_u(cur.q[7].z, j);
-            const uint32_t tri = bcast_u(cur.tri, j);
-            const bool well_scaled = ruz != 0.0;          // wave-uniform
-            const int x0 = max((int)(bb0 & 0xffff), px0), x1 = min((int)(bb1 & 0xffff), xa1);
-            const int y0 = max((int)(bb0 >> 16), ya0), y1 = min((int)(bb1 >> 16), ya1);
-            for (int by = y0; by <= y1; by += 8) {
-                for (int bx = x0; bx <= x1; bx += 8) {
-                    const int x = bx + (lane & 7), y = by + (lane >> 3);
-                    const bool act = (x <= x1) && (y <= y1);
-                    // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
-                    const double pxc = (double)x + 0.5, pyc = (double)y + 0.5;        // :149
-                    const double s0z = r_ax - pxc, s1z = r_ay - pyc;
-                    const double ux = r_s0y * s1z - s0z * r_s1y;                      // geometry.h:145
-                    const double uy = s0z * r_s1x - r_s0x * s1z;                      // geometry.h:146
-                    const double us = ux + uy;
-                    double b0, b1, b2;
-                    bool cov;
-                    if (well_scaled) {
-                        // u.z < 0 and nothing can over/underflow, so the signs of the quotients are known
-                        // without dividing: u.y/u.z < 0 <=> u.y > 0, u.x/u.z < 0 <=> u.x > 0, and
-                        // 1 - RN(us/u.z) < 0 <=> RN(us/u.z) > 1 <=> us < u.z  ("exactness").
-                        cov = act && !(us < uz) && !(uy > 0.0) && !(ux > 0.0);        // :152
-                        if (__ballot(cov) == 0) continue;        // whole 8x8 block outside: no division at all
-                        b0 = 1.0 - div_by_uz(us, uz, ruz);
-                        b1 = div_by_uz(uy, uz, ruz);
-                        b2 = div_by_uz(ux, uz, ruz);
-                    } else {
-                        b0 = 1.0 - us / uz;                                           // :85, as written
-                        b1 = uy / uz;
-                        b2 = ux / uz;
-                        cov = act && !(b0 < 0 || b1 < 0 || b2 < 0);                   // :152
-                    }
-                    const double z = b0 * r_z0 + b1 * r_z1 + b2 * r_z2;               // :156-158
-                    cov = cov && __builtin_isfinite(z);                               // :160
-                    if (__ballot(cov) == 0) continue;
-                    const int li = lds_index(x, y);
-                    const double zold = zt[li];
-                    if (cov && (z < zold)) {                                          // :165
-                        uint32_t color;
-                        if (FLAT_ONLY) {
-                            color = r_color;
-                        } else {
-                            const uint32_t dl = bcast_u(cur.q[7].w, j);
-                            const DrawDesc& d = draws[dl >> 24];
-                            if (d.kind == TRGL_SHADER_FLAT) {
-                                color = r_color;
-                            } else {
-                                const uint32_t local = dl & 0xffffffu;
-                                const double iw0 = bcast_d(cur.q[5].z, cur.q[5].w, j), iw1 = bcast_d(cur.q[6].x, cur.q[6].y, j),
-                                             iw2 = bcast_d(cur.q[6].z, cur.q[6].w, j);
-                                double pc[3];
-                                const double denom = b0 * iw0 + b1 * iw1 + b2 * iw2;              // :172-174
-                                if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }  // :177-185
-                                else { pc[0] = (b0 * iw0) / denom; pc[1] = (b1 * iw1) / denom; pc[2] = (b2 * iw2) / denom; }
-                                const double* vary = d.vary + (size_t)local * d.K;
-                                if (d.kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(d.colors ? d.colors[local] : 0xffffffffu, vary, pc);
-                                else if (d.kind == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
-                                else color = frag_eye(d.u, tex, vary, pc).bgra;
-                            }
-                        }
-                        zt[li] = z;                                                   // :191
-                        ct[li] = color;                                               // :192
-                        ++frags;                                                      // :194
-                        zmin = dmin(zmin, z); zmax = dmax(zmax, z);                   // :197-198
-                        if (z == 0.0 && !zero_locked) {       // rare: remember which signed zero came first
-                            unsigned long long order = ((unsigned long long)tri << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
-                            atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
-                        }
-                    }
-                }
+            TriConst T;
+            T.ax = bcast_d(cur.q[0].x, cur.q[0].y, j); T.ay = bcast_d(cur.q[0].z, cur.q[0].w, j);
+            T.s0x = bcast_d(cur.q[1].x, cur.q[1].y, j); T.s0y = bcast_d(cur.q[1].z, cur.q[1].w, j);
+            T.s1x = bcast_d(cur.q[2].x, cur.q[2].y, j); T.s1y = bcast_d(cur.q[2].z, cur.q[2].w, j);
+            T.uz = bcast_d(cur.q[3].x, cur.q[3].y, j); T.ruz = bcast_d(cur.q[3].z, cur.q[3].w, j);
+            T.z0 = bcast_d(cur.q[4].x, cur.q[4].y, j); T.z1 = bcast_d(cur.q[4].z, cur.q[4].w, j);
+            T.z2 = bcast_d(cur.q[5].x, cur.q[5].y, j);
+            if (!FLAT_ONLY) {
+                T.iw0 = bcast_d(cur.q[5].z, cur.q[5].w, j); T.iw1 = bcast_d(cur.q[6].x, cur.q[6].y, j);
+                T.iw2 = bcast_d(cur.q[6].z, cur.q[6].w, j); T.dl = bcast_u(cur.q[7].w, j);
             }
+            T.bb0 = bcast_u(cur.q[7].x, j); T.bb1 = bcast_u(cur.q[7].y, j); T.color = bcast_u(cur.q[7].z, j);
+            T.tri = bcast_u(cur.tri, j);
+            if (T.ruz != 0.0) raster_triangle<FLAT_ONLY, true>(T, S, draws, tex, stats);    // wave-uniform
+            else raster_triangle<FLAT_ONLY, false>(T, S, draws, tex, stats);
         }
         cur = nxt;
     }
+
+    uint32_t frags = S.frags;
+    const double zmin = S.zmin, zmax = S.zmax;
 
     // ---- tile out: row-contiguous stores --------------------------------------------------------
     const bool full_x = (px0 + TRGL_TILE - 1) <= xa1;
