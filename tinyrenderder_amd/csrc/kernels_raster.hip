@@ -265,7 +265,8 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, TileState& S,
                 const double z = b0 * T.z0 + b1 * T.z1 + b2 * T.z2;           // :156-158
                 const int li = lds_index(x, y);
                 const double zold = S.zt[li];
-                if (__builtin_isfinite(z) && (z < zold)) {                    // :160, :165
+                // :160 — on the well-scaled path b0..b2 and the NDC depths are finite and bounded, so z is finite
+                if ((WELL_SCALED || __builtin_isfinite(z)) && (z < zold)) {   // :165
                     uint32_t color;
                     if (FLAT_ONLY) {
                         color = T.color;
@@ -288,10 +289,15 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, TileState& S,
                     S.zt[li] = z;                                             // :191
                     S.ct[li] = color;                                         // :192
                     ++S.frags;                                                // :194
-                    S.zmin = dmin(S.zmin, z); S.zmax = dmax(S.zmax, z);       // :197-198
-                    if (z == 0.0 && !S.zero_locked) {       // rare: remember which signed zero came first
-                        unsigned long long order = ((unsigned long long)T.tri << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
-                        atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
+                    // :197-198.  After a few fragments a lane's running min/max rarely moves, so the updates
+                    // live in a branch.  A written zero can only end up as a z-range end if it is a new min or
+                    // max of its lane when it is written, so the first-zero bookkeeping lives there too.
+                    if ((z < S.zmin) || (S.zmax < z)) {
+                        S.zmin = dmin(S.zmin, z); S.zmax = dmax(S.zmax, z);
+                        if (z == 0.0 && !S.zero_locked) {
+                            unsigned long long order = ((unsigned long long)T.tri << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
+                            atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
+                        }
                     }
                 }
             }
