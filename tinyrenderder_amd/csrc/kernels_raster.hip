@@ -311,20 +311,29 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                                                 const uint32_t* __restrict__ tile_start,
                                                 const uint32_t* __restrict__ tile_end,
                                                 const DrawDesc* __restrict__ draws,
-                                                const DevTexture* __restrict__ tex, DevStats* __restrict__ stats) {
+                                                const DevTexture* __restrict__ tex, DevStats* __restrict__ stats,
+                                                const uint32_t* __restrict__ items, const uint32_t* __restrict__ n_items) {
     __shared__ __attribute__((aligned(16))) double   s_z[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
     __shared__ __attribute__((aligned(16))) uint32_t s_c[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile_x = blockIdx.x * TRGL_WAVES_PER_BLOCK + w;
-    const int tile_y = fp.strip_ty0 + blockIdx.y;
-    if (tile_x >= fp.tiles_x) return;                    // no block-level barrier is used below
-    const int t = tile_y * fp.tiles_x + tile_x;
+    // One wave = one work item = (tile, band of rows).  Ordinary tiles are one item; tiles whose triangle list is
+    // much longer than the average are cut into 2..16 horizontal bands (k_make_items) so that a few dense tiles
+    // (mesh silhouettes) do not serialise the frame: every band walks the same list and skips, after two
+    // v_readlane, the triangles that miss its rows.
+    const uint32_t item_idx = blockIdx.x * TRGL_WAVES_PER_BLOCK + w;
+    if (item_idx >= *n_items) return;                    // no block-level barrier is used below
+    const uint32_t item = items[item_idx];
+    const int t = (int)(item & 0xffffffu);
+    const int band = (int)((item >> 24) & 0xf), band_log2 = (int)(item >> 28);
+    const int tile_y = t / fp.tiles_x, tile_x = t - tile_y * fp.tiles_x;
     const int px0 = tile_x << TRGL_TILE_LOG2, py0 = tile_y << TRGL_TILE_LOG2;
-    // rows / columns of this tile that exist and belong to this context's strip
+    const int band_rows = TRGL_TILE >> band_log2;
+    // rows / columns of this item that exist and belong to this context's strip
     const int xa1 = min(px0 + TRGL_TILE - 1, fp.W - 1);
-    const int ya0 = max(py0, fp.strip_y0), ya1 = min(min(py0 + TRGL_TILE - 1, fp.H - 1), fp.strip_y1 - 1);
+    const int ya0 = max(py0 + band * band_rows, fp.strip_y0);
+    const int ya1 = min(min(py0 + (band + 1) * band_rows - 1, fp.H - 1), fp.strip_y1 - 1);
 
     uint32_t beg = tile_start[t], end = tile_end[t];
     if (!fp.init_from_clear && beg == end) return;       // nothing to composite onto this tile
@@ -509,6 +518,34 @@ __global__ void k_selftest_division(unsigned long long n_per_thread, unsigned lo
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// Work items of the raster kernel: one per tile row-band (see k_raster).  A tile is cut into bands when its list
+// is longer than `split_len` (chosen by the host relative to the mean list length).  Tiles outside the strip's
+// tile rows, and empty tiles of a flush that does not start from clear, get no item.
+__global__ __launch_bounds__(256) void k_make_items(FrameParams fp, const uint32_t* __restrict__ tile_start,
+                                                    const uint32_t* __restrict__ tile_end, uint32_t split_len,
+                                                    uint32_t* __restrict__ items, uint32_t* __restrict__ n_items) {
+    const int ntiles_strip = (fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t nb = 0, bl = 0, t = 0;
+    if (k < ntiles_strip) {
+        t = (uint32_t)(fp.strip_ty0 * fp.tiles_x + k);
+        const uint32_t n = tile_end[t] - tile_start[t];
+        if (n || fp.init_from_clear) {
+            while (bl < 4 && (n >> bl) > split_len) ++bl;      // 1, 2, 4, 8 or 16 bands
+            nb = 1u << bl;
+        }
+    }
+    // wave-aggregated append (order of items is irrelevant)
+    uint32_t inc = nb;
+    const int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    const uint32_t total = __shfl(inc, 63);
+    uint32_t base = 0;
+    if (lane == 63 && total) base = atomicAdd(n_items, total);
+    base = __shfl(base, 63) + inc - nb;
+    for (uint32_t b = 0; b < nb; ++b) items[base + b] = t | (b << 24) | (bl << 28);
+}
+
 // after the raster kernel of a flush: fix the sign of a zero z-range end (see DevStats)
 __global__ void k_fold_stats(DevStats* __restrict__ s) {
     if (!s->zero_locked && (s->zero_pos_key != TRGL_ZERO_KEY_EMPTY || s->zero_neg_key != TRGL_ZERO_KEY_EMPTY)) {
@@ -527,16 +564,27 @@ void launch_selftest_division(hipStream_t s, unsigned long long n_per_thread, un
     hipLaunchKernelGGL(k_selftest_division, dim3(1024), dim3(256), 0, s, n_per_thread, seed, mismatches);
 }
 
+uint32_t raster_max_items(const FrameParams& fp, uint64_t pairs, uint32_t split_len) {
+    const uint64_t tiles = (uint64_t)(fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x;
+    // a tile with n entries makes at most max(1, 2n/split_len) bands (<= 16)
+    uint64_t extra = split_len ? 2 * pairs / split_len : 0;
+    if (extra > tiles * 15) extra = tiles * 15;
+    return (uint32_t)(tiles + extra);
+}
+
 void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const TriRec* recs, const uint32_t* vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
-                   const DevTexture* tex, DevStats* stats) {
-    int rows = fp.strip_ty1 - fp.strip_ty0;
-    if (rows <= 0) return;
-    dim3 grid((fp.tiles_x + TRGL_WAVES_PER_BLOCK - 1) / TRGL_WAVES_PER_BLOCK, rows);
+                   const DevTexture* tex, DevStats* stats, uint32_t split_len, uint32_t max_items, uint32_t* items,
+                   uint32_t* n_items) {
+    const int tiles = (fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x;
+    if (tiles <= 0) return;
+    (void)hipMemsetAsync(n_items, 0, 4, s);
+    hipLaunchKernelGGL(k_make_items, dim3((tiles + 255) / 256), dim3(256), 0, s, fp, tile_start, tile_end, split_len, items, n_items);
+    dim3 grid((max_items + TRGL_WAVES_PER_BLOCK - 1) / TRGL_WAVES_PER_BLOCK);
     if (flat_only)
-        hipLaunchKernelGGL(k_raster<true>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats);
+        hipLaunchKernelGGL(k_raster<true>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items);
     else
-        hipLaunchKernelGGL(k_raster<false>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats);
+        hipLaunchKernelGGL(k_raster<false>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items);
     hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(1), 0, s, stats);
 }
 

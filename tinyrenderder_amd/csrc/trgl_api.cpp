@@ -52,6 +52,7 @@ struct trgl_ctx {
     uint32_t* hist = nullptr; size_t cap_hist = 0;
     uint32_t* scan_tmp = nullptr; size_t cap_scan = 0;
     uint32_t* tile_start = nullptr; uint32_t* tile_end = nullptr;
+    uint32_t* items = nullptr; size_t cap_items = 0; uint32_t* n_items = nullptr;
     DrawDesc* draws_dev = nullptr;
     DrawDesc* draws_pinned = nullptr;
     DevStats* stats_dev = nullptr;
@@ -146,6 +147,7 @@ int trgl_create(int device, int width, int height, int bpp, trgl_ctx** out) {
     CRE(hipMemset(c->tex_dev, 0, sizeof(c->tex_host)));
     CRE(hipMalloc((void**)&c->tile_start, ntiles * 4));
     CRE(hipMalloc((void**)&c->tile_end, ntiles * 4));
+    CRE(hipMalloc((void**)&c->n_items, 4));
     CRE(hipMalloc((void**)&c->draws_dev, sizeof(DrawDesc) * TRGL_MAX_DRAWS));
     CRE(hipHostMalloc((void**)&c->draws_pinned, sizeof(DrawDesc) * TRGL_MAX_DRAWS));
     CRE(hipMalloc((void**)&c->stats_dev, sizeof(DevStats)));
@@ -166,7 +168,7 @@ int trgl_destroy(trgl_ctx* c) {
     for (auto& s : c->stage) (void)hipFree(s.base);
     for (int i = 0; i < TRGL_MAX_TEXTURES; ++i) if (c->tex_host[i].data) (void)hipFree((void*)c->tex_host[i].data);
     void* ptrs[] = { c->fb, c->zb, c->tex_dev, c->recs, c->cnt, c->off, c->tilebox, c->keys[0], c->keys[1], c->vals[0],
-                     c->vals[1], c->hist, c->scan_tmp, c->tile_start, c->tile_end, c->draws_dev, c->stats_dev };
+                     c->vals[1], c->hist, c->scan_tmp, c->tile_start, c->tile_end, c->draws_dev, c->stats_dev, c->items, c->n_items };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->draws_pinned) (void)hipHostFree(c->draws_pinned);
     if (c->stats_pinned) (void)hipHostFree(c->stats_pinned);
@@ -387,7 +389,14 @@ int trgl_flush(trgl_ctx* c) {
     // valid addresses anyway
     const TriRec* recs_arg = c->recs ? c->recs : reinterpret_cast<const TriRec*>(c->tile_start);
     const uint32_t* vals_arg = (P && c->vals[cur]) ? c->vals[cur] : c->tile_start;
-    launch_raster(s, fp, flat_only, recs_arg, vals_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev);
+    // heavy tiles are cut into row bands when their list is > 4x the mean list length (and > 256 entries)
+    const uint64_t strip_tiles = (uint64_t)(fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x;
+    uint32_t split_len = 256;
+    if (strip_tiles && 4 * (uint64_t)P / strip_tiles > split_len) split_len = (uint32_t)(4 * (uint64_t)P / strip_tiles);
+    const uint32_t max_items = raster_max_items(fp, P, split_len);
+    if ((r = grow(c, c->items, c->cap_items, (size_t)max_items + 64))) return r;
+    launch_raster(s, fp, flat_only, recs_arg, vals_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev,
+                  split_len, max_items, c->items, c->n_items);
     if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[3], s)); c->events_pending = true; }
     HIPCHK(c, hipGetLastError());
 
