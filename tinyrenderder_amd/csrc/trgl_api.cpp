@@ -389,10 +389,12 @@ int trgl_flush(trgl_ctx* c) {
     // valid addresses anyway
     const TriRec* recs_arg = c->recs ? c->recs : reinterpret_cast<const TriRec*>(c->tile_start);
     const uint32_t* vals_arg = (P && c->vals[cur]) ? c->vals[cur] : c->tile_start;
-    // heavy tiles are cut into row bands when their list is > 4x the mean list length (and > 256 entries)
+    // A lone wave needs ~1-3 us per list entry (one long dependent fp64 chain); throughput comes from many waves.
+    // So lists longer than twice the mean list length (at least 8 entries) are cut into 2..16 row bands: dense
+    // uniform scenes (C4: 1100 entries in every tile) never split, sparse or uneven ones (meshes) get parallelism.
     const uint64_t strip_tiles = (uint64_t)(fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x;
-    uint32_t split_len = 256;
-    if (strip_tiles && 4 * (uint64_t)P / strip_tiles > split_len) split_len = (uint32_t)(4 * (uint64_t)P / strip_tiles);
+    uint32_t split_len = 8;
+    if (strip_tiles && 2 * (uint64_t)P / strip_tiles > split_len) split_len = (uint32_t)(2 * (uint64_t)P / strip_tiles);
     const uint32_t max_items = raster_max_items(fp, P, split_len);
     if ((r = grow(c, c->items, c->cap_items, (size_t)max_items + 64))) return r;
     launch_raster(s, fp, flat_only, recs_arg, vals_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev,
