@@ -312,7 +312,8 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                                                 const uint32_t* __restrict__ tile_end,
                                                 const DrawDesc* __restrict__ draws,
                                                 const DevTexture* __restrict__ tex, DevStats* __restrict__ stats,
-                                                const uint32_t* __restrict__ items, const uint32_t* __restrict__ n_items) {
+                                                const uint32_t* __restrict__ items, const uint32_t* __restrict__ n_items,
+                                                unsigned long long* __restrict__ item_stats) {
     __shared__ __attribute__((aligned(16))) double   s_z[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
     __shared__ __attribute__((aligned(16))) uint32_t s_c[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
 
@@ -336,7 +337,13 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
     const int ya1 = min(min(py0 + (band + 1) * band_rows - 1, fp.H - 1), fp.strip_y1 - 1);
 
     uint32_t beg = tile_start[t], end = tile_end[t];
-    if (!fp.init_from_clear && beg == end) return;       // nothing to composite onto this tile
+    if (!fp.init_from_clear && beg == end) {             // nothing to composite onto this tile (k_make_items skips these)
+        if (lane == 0) {
+            ulonglong2* dst = reinterpret_cast<ulonglong2*>(item_stats + (size_t)item_idx * 4);
+            dst[0] = make_ulonglong2(0ull, ~0ull); dst[1] = make_ulonglong2(0ull, 0ull);
+        }
+        return;
+    }
 
     double* zt = s_z[w];
     uint32_t* ct = s_c[w];
@@ -461,12 +468,12 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
         unsigned long long a = __shfl_xor(kmin, o); kmin = a < kmin ? a : kmin;
         unsigned long long b = __shfl_xor(kmax, o); kmax = b > kmax ? b : kmax;
     }
-    if (lane == 0 && frags) {
-        atomicAdd(&stats->fragments, (unsigned long long)frags);
-        // same-address atomics serialise: skip the ones that cannot change the value (stale reads are safe,
-        // the keys only move one way)
-        if (kmin < __builtin_nontemporal_load(&stats->zmin_key)) atomicMin(&stats->zmin_key, kmin);
-        if (kmax > __builtin_nontemporal_load(&stats->zmax_key)) atomicMax(&stats->zmax_key, kmax);
+    // one partial per work item, reduced by k_fold_stats: same-address atomics from thousands of items would
+    // serialise at ~11 ns each
+    if (lane == 0) {
+        ulonglong2* dst = reinterpret_cast<ulonglong2*>(item_stats + (size_t)item_idx * 4);
+        dst[0] = make_ulonglong2((unsigned long long)frags, kmin);
+        dst[1] = make_ulonglong2(kmax, 0ull);
     }
 }
 
@@ -546,14 +553,42 @@ __global__ __launch_bounds__(256) void k_make_items(FrameParams fp, const uint32
     for (uint32_t b = 0; b < nb; ++b) items[base + b] = t | (b << 24) | (bl << 28);
 }
 
-// after the raster kernel of a flush: fix the sign of a zero z-range end (see DevStats)
-__global__ void k_fold_stats(DevStats* __restrict__ s) {
-    if (!s->zero_locked && (s->zero_pos_key != TRGL_ZERO_KEY_EMPTY || s->zero_neg_key != TRGL_ZERO_KEY_EMPTY)) {
-        s->zero_sign = s->zero_neg_key < s->zero_pos_key ? 1u : 0u;
-        s->zero_locked = 1u;
+// after the raster kernel of a flush: fold the per-item partials into the context's counters (our_gl.cpp:194-198)
+// and fix the sign of a zero z-range end (see DevStats).  One block.
+__global__ __launch_bounds__(1024) void k_fold_stats(DevStats* __restrict__ s, const uint32_t* __restrict__ n_items,
+                                                     const unsigned long long* __restrict__ item_stats) {
+    __shared__ unsigned long long sh[3][16];
+    const uint32_t n = *n_items;
+    unsigned long long fr = 0, kmin = ~0ull, kmax = 0ull;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const ulonglong2 a = reinterpret_cast<const ulonglong2*>(item_stats + (size_t)i * 4)[0];
+        const unsigned long long c = item_stats[(size_t)i * 4 + 2];
+        fr += a.x; kmin = a.y < kmin ? a.y : kmin; kmax = c > kmax ? c : kmax;
     }
-    s->zero_pos_key = TRGL_ZERO_KEY_EMPTY;
-    s->zero_neg_key = TRGL_ZERO_KEY_EMPTY;
+    for (int o = 32; o; o >>= 1) {
+        fr += __shfl_xor(fr, o);
+        unsigned long long a = __shfl_xor(kmin, o); kmin = a < kmin ? a : kmin;
+        unsigned long long b = __shfl_xor(kmax, o); kmax = b > kmax ? b : kmax;
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sh[0][w] = fr; sh[1][w] = kmin; sh[2][w] = kmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) {
+            fr += sh[0][k]; kmin = sh[1][k] < kmin ? sh[1][k] : kmin; kmax = sh[2][k] > kmax ? sh[2][k] : kmax;
+        }
+        s->fragments += fr;
+        if (fr) {       // items without fragments carry the neutral keys
+            if (kmin < s->zmin_key) s->zmin_key = kmin;
+            if (kmax > s->zmax_key) s->zmax_key = kmax;
+        }
+        if (!s->zero_locked && (s->zero_pos_key != TRGL_ZERO_KEY_EMPTY || s->zero_neg_key != TRGL_ZERO_KEY_EMPTY)) {
+            s->zero_sign = s->zero_neg_key < s->zero_pos_key ? 1u : 0u;
+            s->zero_locked = 1u;
+        }
+        s->zero_pos_key = TRGL_ZERO_KEY_EMPTY;
+        s->zero_neg_key = TRGL_ZERO_KEY_EMPTY;
+    }
 }
 
 }  // namespace
@@ -575,17 +610,17 @@ uint32_t raster_max_items(const FrameParams& fp, uint64_t pairs, uint32_t split_
 void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const TriRec* recs, const uint32_t* vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
                    const DevTexture* tex, DevStats* stats, uint32_t split_len, uint32_t max_items, uint32_t* items,
-                   uint32_t* n_items) {
+                   uint32_t* n_items, unsigned long long* item_stats) {
     const int tiles = (fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x;
     if (tiles <= 0) return;
     (void)hipMemsetAsync(n_items, 0, 4, s);
     hipLaunchKernelGGL(k_make_items, dim3((tiles + 255) / 256), dim3(256), 0, s, fp, tile_start, tile_end, split_len, items, n_items);
     dim3 grid((max_items + TRGL_WAVES_PER_BLOCK - 1) / TRGL_WAVES_PER_BLOCK);
     if (flat_only)
-        hipLaunchKernelGGL(k_raster<true>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items);
+        hipLaunchKernelGGL(k_raster<true>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items, item_stats);
     else
-        hipLaunchKernelGGL(k_raster<false>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items);
-    hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(1), 0, s, stats);
+        hipLaunchKernelGGL(k_raster<false>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items, item_stats);
+    hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(1024), 0, s, stats, n_items, item_stats);
 }
 
 }  // namespace trgl

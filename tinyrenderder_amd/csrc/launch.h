@@ -25,7 +25,7 @@ uint32_t raster_max_items(const FrameParams& fp, uint64_t pairs, uint32_t split_
 void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const TriRec* recs, const uint32_t* vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
                    const DevTexture* tex, DevStats* stats, uint32_t split_len, uint32_t max_items, uint32_t* items,
-                   uint32_t* n_items);
+                   uint32_t* n_items, unsigned long long* item_stats);
 
 void launch_selftest_division(hipStream_t s, unsigned long long n_per_thread, unsigned long long seed,
                               unsigned long long* mismatches);

@@ -53,6 +53,7 @@ struct trgl_ctx {
     uint32_t* scan_tmp = nullptr; size_t cap_scan = 0;
     uint32_t* tile_start = nullptr; uint32_t* tile_end = nullptr;
     uint32_t* items = nullptr; size_t cap_items = 0; uint32_t* n_items = nullptr;
+    unsigned long long* item_stats = nullptr; size_t cap_item_stats = 0;
     DrawDesc* draws_dev = nullptr;
     DrawDesc* draws_pinned = nullptr;
     DevStats* stats_dev = nullptr;
@@ -168,7 +169,7 @@ int trgl_destroy(trgl_ctx* c) {
     for (auto& s : c->stage) (void)hipFree(s.base);
     for (int i = 0; i < TRGL_MAX_TEXTURES; ++i) if (c->tex_host[i].data) (void)hipFree((void*)c->tex_host[i].data);
     void* ptrs[] = { c->fb, c->zb, c->tex_dev, c->recs, c->cnt, c->off, c->tilebox, c->keys[0], c->keys[1], c->vals[0],
-                     c->vals[1], c->hist, c->scan_tmp, c->tile_start, c->tile_end, c->draws_dev, c->stats_dev, c->items, c->n_items };
+                     c->vals[1], c->hist, c->scan_tmp, c->tile_start, c->tile_end, c->draws_dev, c->stats_dev, c->items, c->n_items, c->item_stats };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->draws_pinned) (void)hipHostFree(c->draws_pinned);
     if (c->stats_pinned) (void)hipHostFree(c->stats_pinned);
@@ -397,8 +398,9 @@ int trgl_flush(trgl_ctx* c) {
     if (strip_tiles && 2 * (uint64_t)P / strip_tiles > split_len) split_len = (uint32_t)(2 * (uint64_t)P / strip_tiles);
     const uint32_t max_items = raster_max_items(fp, P, split_len);
     if ((r = grow(c, c->items, c->cap_items, (size_t)max_items + 64))) return r;
+    if ((r = grow(c, c->item_stats, c->cap_item_stats, ((size_t)max_items + 64) * 4))) return r;
     launch_raster(s, fp, flat_only, recs_arg, vals_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev,
-                  split_len, max_items, c->items, c->n_items);
+                  split_len, max_items, c->items, c->n_items, c->item_stats);
     if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[3], s)); c->events_pending = true; }
     HIPCHK(c, hipGetLastError());
 
