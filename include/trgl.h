@@ -142,6 +142,20 @@ int trgl_draw(trgl_ctx* ctx, int shader_kind, const trgl_uniforms* uniforms,
               const double* clip, const double* varyings, const uint32_t* colors,
               uint64_t n, int mem_kind);
 
+/* SURVEY.md §8(f) N1 — the vertex stage on the device.
+ * Replaces: the face loop `for v in 0..2: clip[v] = shader.vertex(face, v); rasterize(clip, shader, framebuffer)`
+ * (main.cpp:660-666,692-698,715-721) with PhongShader::vertex / EyeShader::vertex (main.cpp:71-90,199-218):
+ * eye = ModelView*(p,1), normal_eye = ModelView*(n,0), clip = projection*eye, for an indexed mesh.
+ *   uniforms->model_view : the global ModelView (used by vertex AND fragment stage, as in the reference)
+ *   projection           : the global Perspective, row-major 4x4
+ *   vertices             : n_vertices x vertex_stride doubles; position at +0, normal at +3, texcoord at +6
+ *                          (the reference's `Vertex`, model.h:14-20, has stride 14)
+ *   indices              : 3*n_faces uint32 (Model::indices, model.h:115)
+ * shader_kind is TRGL_SHADER_PHONG or TRGL_SHADER_EYE.  Host arrays are copied before return. */
+int trgl_draw_indexed(trgl_ctx* ctx, int shader_kind, const trgl_uniforms* uniforms, const double projection[16],
+                      const double* vertices, int vertex_stride, uint64_t n_vertices,
+                      const uint32_t* indices, uint64_t n_faces, int mem_kind);
+
 /* Execute everything submitted so far (asynchronously on the context's stream). */
 int trgl_flush(trgl_ctx* ctx);
 /* Wait for the context's stream. */
@@ -182,6 +196,24 @@ int trgl_get_phase_ms(trgl_ctx* ctx, double ms[TRGL_NUM_PHASES], uint64_t* flush
 int trgl_reset_phase_ms(trgl_ctx* ctx);
 /* Implementation traffic counters of the last flush: tri-tile pairs produced by binning. */
 int trgl_get_last_flush_info(trgl_ctx* ctx, uint64_t* triangles, uint64_t* pairs, uint64_t* tiles);
+
+/* ---- post-process on the resident z-buffer ----------------------------------- */
+
+/* The reference's SSAO constants (main.cpp:317-321); trgl_ssao_defaults fills them in. */
+typedef struct trgl_ssao_params {
+    int32_t num_directions;        /* AO_NUM_DIRECTIONS = 8 (at most 16) */
+    int32_t steps_per_direction;   /* AO_STEPS_PER_DIRECTION = 8 */
+    double  sample_radius;         /* AO_SAMPLE_RADIUS = 16.0 px */
+    double  occlusion_threshold;   /* AO_OCCLUSION_THRESHOLD = 1e-3 */
+    double  intensity;             /* AO_INTENSITY = 0.35 */
+} trgl_ssao_params;
+void trgl_ssao_defaults(trgl_ssao_params* p);
+
+/* Replaces: save_zbuffer_image's pixel loop (main.cpp:269-311), the SSAO loop (main.cpp:317-362,757-763) and the
+ * final composite (main.cpp:768-783), computed on the device from the context's z-buffer and framebuffer (no
+ * z-buffer readback).  Each output is W*H*3 bytes (B,G,R) in host memory and may be NULL; `final` needs `ao` to be
+ * computed too (it is, internally).  params NULL = the reference's constants.  Implies flush + sync. */
+int trgl_postprocess(trgl_ctx* ctx, const trgl_ssao_params* params, uint8_t* zbuffer_image, uint8_t* ao_map, uint8_t* final_image);
 
 /* ---- TGA writer (host only) ------------------------------------------------ */
 

@@ -87,6 +87,10 @@ def lib():
         L.orc_interp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_tga_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_tga_encode.restype = C.c_uint64
+        L.orc_vertex_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.orc_zbuffer_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_ssao.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_composite.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -235,3 +239,30 @@ def run_reference_tga(img: np.ndarray, vflip=True, rle=True) -> bytes:
             f.write(img.tobytes())
         subprocess.run([REF_HARNESS, "tga", ip, op], check=True)
         return open(op, "rb").read()
+
+
+def vertex_stage(model_view, projection, vertices, indices):
+    """main.cpp:71-90 for an indexed mesh; vertices [nv, stride>=8] (pos3, nrm3, uv2, ...), indices [nf,3] uint32."""
+    mv = np.ascontiguousarray(model_view, np.float64).reshape(16)
+    pj = np.ascontiguousarray(projection, np.float64).reshape(16)
+    v = np.ascontiguousarray(vertices, np.float64)
+    idx = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
+    nf = idx.shape[0]
+    clip, vary = np.empty((nf, 12)), np.empty((nf, 24))
+    lib().orc_vertex_stage(mv.ctypes.data, pj.ctypes.data, v.ctypes.data, v.shape[1], idx.ctypes.data, nf, clip.ctypes.data, vary.ctypes.data)
+    return clip, vary
+
+
+def zbuffer_image(z):
+    z = np.ascontiguousarray(z, np.float64); h, w = z.shape
+    out = np.empty((h, w, 3), np.uint8); lib().orc_zbuffer_image(z.ctypes.data, w, h, out.ctypes.data); return out
+
+
+def ssao(z):
+    z = np.ascontiguousarray(z, np.float64); h, w = z.shape
+    out = np.empty((h, w, 3), np.uint8); lib().orc_ssao(z.ctypes.data, w, h, out.ctypes.data); return out
+
+
+def composite(fb, ao):
+    fb = np.ascontiguousarray(fb, np.uint8); ao = np.ascontiguousarray(ao, np.uint8); h, w, _ = fb.shape
+    out = np.empty((h, w, 3), np.uint8); lib().orc_composite(fb.ctypes.data, ao.ctypes.data, w, h, out.ctypes.data); return out

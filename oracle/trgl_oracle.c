@@ -9,6 +9,9 @@
 
 #include <limits.h>
 #include <math.h>
+#ifndef M_PI
+#define M_PI 3.14159265358979323846   /* our_gl.h:10-12 */
+#endif
 #include <string.h>
 
 /* (int)double as the reference's x86-64 build executes it (cvttsd2si): values that do not fit
@@ -429,4 +432,83 @@ uint64_t orc_tga_encode(const uint8_t* data, int w, int h, int bpp, int vflip, i
         }
     }
     return n;
+}
+
+/* ---- N1: vertex stage, main.cpp:71-90 (Phong) == main.cpp:199-218 (Eye) ------------------------------ */
+void orc_vertex_stage(const double mv[16], const double proj[16], const double* vertices, int stride,
+                      const uint32_t* indices, uint64_t nfaces, double* clip, double* varyings) {
+    for (uint64_t f = 0; f < nfaces; ++f) {
+        double* uv = varyings + 24 * f;        /* varying_uv[3]           */
+        double* pe = uv + 6;                   /* varying_position_eye[3] */
+        double* ne = uv + 15;                  /* varying_normal_eye[3]   */
+        for (int v = 0; v < 3; ++v) {
+            const double* vert = vertices + (size_t)indices[3 * f + v] * stride;     /* model.cpp:396-412 */
+            double p4[4] = { vert[0], vert[1], vert[2], 1.0 }, n4[4] = { vert[3], vert[4], vert[5], 0.0 };
+            double eye[4], nrm[4];
+            for (int r = 0; r < 4; ++r) { eye[r] = dot4(mv + 4 * r, p4); nrm[r] = dot4(mv + 4 * r, n4); }   /* :77-86 */
+            uv[2 * v] = vert[6]; uv[2 * v + 1] = vert[7];                              /* :75 */
+            for (int k = 0; k < 3; ++k) { pe[3 * v + k] = eye[k]; ne[3 * v + k] = nrm[k]; }   /* :81,87 */
+            for (int r = 0; r < 4; ++r) clip[12 * f + 4 * v + r] = dot4(proj + 4 * r, eye);   /* :89 */
+        }
+    }
+}
+
+/* ---- N4: main.cpp:269-311 ------------------------------------------------------------------------------ */
+void orc_zbuffer_image(const double* zbuf, int w, int h, uint8_t* out) {
+    double min_depth = 1e9, max_depth = -1e9;
+    size_t n = (size_t)w * h;
+    for (size_t i = 0; i < n; ++i) {
+        double depth = zbuf[i];
+        if (isfinite(depth)) { min_depth = dmin(min_depth, depth); max_depth = dmax(max_depth, depth); }
+    }
+    if (!isfinite(min_depth)) { memset(out, 255, n * 3); return; }           /* :284-292 (unreachable: 1e9 is finite) */
+    if (max_depth - min_depth < 1e-7) max_depth = min_depth + 1e-7;           /* :294-296 */
+    for (size_t i = 0; i < n; ++i) {
+        double depth = zbuf[i];
+        unsigned char value = 255;
+        if (isfinite(depth)) {
+            double normalized = (depth - min_depth) / (max_depth - min_depth);
+            value = (unsigned char)(255.0 * (1.0 - normalized));
+        }
+        out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = value;
+    }
+}
+
+/* main.cpp:317-362 */
+static double compute_ssao_at(const double* zbuffer, int width, int height, int pixel_x, int pixel_y) {
+    double center_depth = zbuffer[pixel_x + (size_t)pixel_y * width];
+    if (!isfinite(center_depth)) return 1.0;
+    int occluded_samples = 0, total_samples = 0;
+    for (int direction = 0; direction < 8; ++direction) {
+        double angle = 2.0 * M_PI * direction / 8;
+        double dir_x = cos(angle), dir_y = sin(angle);
+        for (int step = 1; step <= 8; ++step) {
+            double radius = (double)step / 8 * 16.0;
+            int sample_x = (int)round(pixel_x + dir_x * radius);
+            int sample_y = (int)round(pixel_y + dir_y * radius);
+            if (sample_x < 0 || sample_x >= width || sample_y < 0 || sample_y >= height) continue;
+            double sample_depth = zbuffer[sample_x + (size_t)sample_y * width];
+            if (!isfinite(sample_depth)) { total_samples++; continue; }
+            if (sample_depth < center_depth - 1e-3) occluded_samples++;
+            total_samples++;
+        }
+    }
+    if (total_samples == 0) return 1.0;
+    double occlusion_factor = (double)occluded_samples / (double)total_samples;
+    return 1.0 - occlusion_factor * 0.35;
+}
+void orc_ssao(const double* zbuf, int w, int h, uint8_t* out) {               /* main.cpp:757-763 */
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+        double ao_value = compute_ssao_at(zbuf, w, h, x, y);
+        unsigned char intensity = (unsigned char)(255.0 * ao_value);
+        size_t i = (size_t)x + (size_t)y * w;
+        out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = intensity;
+    }
+}
+void orc_composite(const uint8_t* fb, const uint8_t* ao, int w, int h, uint8_t* out) {   /* main.cpp:771-783 */
+    size_t n = (size_t)w * h;
+    for (size_t i = 0; i < n; ++i) {
+        double ao_factor = ao[3 * i] / 255.0;
+        for (int c = 0; c < 3; ++c) out[3 * i + c] = (unsigned char)dmin(255.0, (double)fb[3 * i + c] * ao_factor);
+    }
 }

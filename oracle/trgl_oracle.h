@@ -63,6 +63,21 @@ void orc_interp(const double* v0, const double* v1, const double* v2, const doub
  * out must hold 18 + w*h*bpp + w*h bytes (worst case); returns the length. */
 uint64_t orc_tga_encode(const uint8_t* data, int w, int h, int bpp, int vflip, int rle, uint8_t* out);
 
+/* ---- SURVEY.md §8(f) next rows, restated from main.cpp (unbuildable here: "parity unpinned" vs a compiled main.cpp) ---- */
+
+/* N1: PhongShader::vertex / EyeShader::vertex (main.cpp:71-90,199-218) for every face-vertex of an indexed mesh.
+ * vertices: nverts x stride doubles, position at +0, normal at +3, texcoord at +6 (model.h:14-20 Vertex);
+ * out clip [nfaces][12], out varyings [nfaces][24] in the layout of include/trgl.h. */
+void orc_vertex_stage(const double mv[16], const double proj[16], const double* vertices, int stride_doubles,
+                      const uint32_t* indices, uint64_t nfaces, double* clip, double* varyings);
+
+/* N4: save_zbuffer_image's pixels (main.cpp:269-311): out = w*h*3 bytes (B,G,R). */
+void orc_zbuffer_image(const double* zbuf, int w, int h, uint8_t* out_bgr);
+/* N4: the SSAO map (main.cpp:317-362,757-763) with the reference's constants; out = w*h*3 bytes. */
+void orc_ssao(const double* zbuf, int w, int h, uint8_t* out_bgr);
+/* N4: final composite (main.cpp:768-783): out = w*h*3 bytes from an RGB framebuffer and the AO map. */
+void orc_composite(const uint8_t* fb_bgr, const uint8_t* ao_bgr, int w, int h, uint8_t* out_bgr);
+
 /* FNV-1a 64 over raw bytes (used for fixtures) */
 uint64_t orc_fnv1a64(const void* p, uint64_t nbytes);
 

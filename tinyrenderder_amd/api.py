@@ -27,7 +27,8 @@ SYMBOLS = [
     "trgl_write_framebuffer", "trgl_read_zbuffer", "trgl_write_zbuffer", "trgl_get_stats", "trgl_reset_stats",
     "trgl_format_stats", "trgl_framebuffer_device_ptr", "trgl_zbuffer_device_ptr", "trgl_stream", "trgl_set_stream",
     "trgl_set_profiling", "trgl_get_phase_ms", "trgl_reset_phase_ms", "trgl_get_last_flush_info",
-    "trgl_selftest_division", "trgl_tga_max_size", "trgl_tga_encode",
+    "trgl_selftest_division", "trgl_tga_max_size", "trgl_tga_encode", "trgl_draw_indexed", "trgl_ssao_defaults",
+    "trgl_postprocess",
 ]
 
 
@@ -50,6 +51,12 @@ class Stats(C.Structure):
         import math
         return (self.triangles_rasterized, self.fragments_drawn, self.min_x, self.min_y, self.max_x, self.max_y,
                 self.min_z, self.max_z, math.copysign(1.0, self.min_z), math.copysign(1.0, self.max_z))
+
+
+class SsaoParams(C.Structure):
+    """trgl_ssao_params"""
+    _fields_ = [("num_directions", C.c_int32), ("steps_per_direction", C.c_int32), ("sample_radius", C.c_double),
+                ("occlusion_threshold", C.c_double), ("intensity", C.c_double)]
 
 
 def make_uniforms(model_view=None, key=(0, 0, 1), fill=(0, 0, 1), rim=(0, 0, 1), normal_map_strength=1.0,
@@ -116,6 +123,10 @@ def load_library(path: str = LIB_PATH):
     L.trgl_reset_phase_ms.argtypes = [vp]
     L.trgl_get_last_flush_info.argtypes = [vp, u64p, u64p, u64p]
     L.trgl_selftest_division.argtypes = [vp, C.c_uint64, C.c_uint64, u64p]
+    L.trgl_draw_indexed.argtypes = [vp, C.c_int, C.POINTER(Uniforms), dp, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int]
+    L.trgl_ssao_defaults.argtypes = [C.POINTER(SsaoParams)]
+    L.trgl_ssao_defaults.restype = None
+    L.trgl_postprocess.argtypes = [vp, C.POINTER(SsaoParams), C.c_void_p, C.c_void_p, C.c_void_p]
     L.trgl_tga_max_size.argtypes = [C.c_int, C.c_int, C.c_int]
     L.trgl_tga_max_size.restype = C.c_size_t
     L.trgl_tga_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_size_t)]
@@ -228,6 +239,31 @@ class Context:
             self._keep.append((clip, varyings, colors))
         self._chk(self.L.trgl_draw(self.h, kind, None if uniforms is None else C.byref(uniforms), _ptr(clip),
                                    _ptr(varyings) if K else None, _ptr(colors), int(n), MEM_DEVICE if device else MEM_HOST))
+
+    def draw_indexed(self, kind, uniforms, projection, vertices, indices, device=False):
+        """Vertex stage on the device (main.cpp:71-90) + draw.  vertices [nv, stride>=8] f64, indices [nf,3] u32."""
+        pj = np.ascontiguousarray(projection, np.float64).reshape(16)
+        if not device:
+            vertices = np.ascontiguousarray(vertices, np.float64)
+            indices = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
+        else:
+            self._keep.append((vertices, indices))
+        nv, stride = vertices.shape
+        nf = indices.shape[0]
+        self._chk(self.L.trgl_draw_indexed(self.h, kind, C.byref(uniforms), pj.ctypes.data_as(C.POINTER(C.c_double)), _ptr(vertices),
+                                           stride, nv, _ptr(indices), nf, MEM_DEVICE if device else MEM_HOST))
+
+    def postprocess(self, zbuffer_image=True, ao=True, final=True, params=None):
+        """main.cpp:269-311,317-362,757-783 on the device; returns dict of [h,w,3] uint8 images."""
+        out = {}
+        shape = (self.height, self.width, 3)
+        zi = np.empty(shape, np.uint8) if zbuffer_image else None
+        a = np.empty(shape, np.uint8) if ao else None
+        f = np.empty(shape, np.uint8) if final else None
+        self._chk(self.L.trgl_postprocess(self.h, None if params is None else C.byref(params),
+                                          None if zi is None else zi.ctypes.data, None if a is None else a.ctypes.data,
+                                          None if f is None else f.ctypes.data))
+        return dict(zbuffer_image=zi, ao=a, final=f)
 
     def flush(self):
         self._chk(self.L.trgl_flush(self.h))

@@ -27,6 +27,13 @@ void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const T
                    const DevTexture* tex, DevStats* stats, uint32_t split_len, uint32_t max_items, uint32_t* items,
                    uint32_t* n_items, unsigned long long* item_stats);
 
+void launch_vertex_stage(hipStream_t s, const double mv[16], const double proj[16], const double* vertices, int stride,
+                         const uint32_t* indices, uint32_t nfaces, double* clip, double* vary);
+void launch_zimage(hipStream_t s, const double* zb, int W, int H, unsigned long long* keys2, uint8_t* out);
+void launch_ssao(hipStream_t s, const double* zb, int W, int H, const double* dir_x, const double* dir_y, int ndir, int steps,
+                 double radius, double threshold, double intensity, uint8_t* out);
+void launch_composite(hipStream_t s, const uint8_t* fb, int bpp, const uint8_t* ao, int W, int H, uint8_t* out);
+
 void launch_selftest_division(hipStream_t s, unsigned long long n_per_thread, unsigned long long seed,
                               unsigned long long* mismatches);
 

@@ -44,6 +44,7 @@ struct trgl_ctx {
     std::vector<DrawDesc> draws;
     uint64_t queued_tris = 0;
     std::vector<StageChunk> stage;
+    int stage_hold = 0;                 // >0 while a draw call has staged data that no DrawDesc references yet
 
     TriRec* recs = nullptr; uint32_t* cnt = nullptr; uint32_t* off = nullptr; uint2* tilebox = nullptr;
     size_t cap_tris = 0;
@@ -243,8 +244,8 @@ static int vary_count(int kind) {
     }
 }
 
-// copy host data into the staging arena (device); chunks live until the flush that uses them is done
-static int stage_copy(trgl_ctx* c, const void* src, size_t bytes, void** dev) {
+// device memory from the per-flush arena; chunks live until the flush that uses them is done
+static int stage_alloc(trgl_ctx* c, size_t bytes, void** dev) {
     size_t need = (bytes + 255) & ~size_t(255);
     StageChunk* ch = nullptr;
     for (auto& s : c->stage) if (s.cap - s.used >= need) { ch = &s; break; }
@@ -254,6 +255,11 @@ static int stage_copy(trgl_ctx* c, const void* src, size_t bytes, void** dev) {
         c->stage.push_back(s); ch = &c->stage.back();
     }
     *dev = ch->base + ch->used; ch->used += need;
+    return TRGL_OK;
+}
+// copy host data into the arena
+static int stage_copy(trgl_ctx* c, const void* src, size_t bytes, void** dev) {
+    int r = stage_alloc(c, bytes, dev); if (r) return r;
     HIPCHK(c, hipMemcpy(*dev, src, bytes, hipMemcpyHostToDevice));   // "copied before trgl_draw returns"
     return TRGL_OK;
 }
@@ -272,6 +278,7 @@ int trgl_draw(trgl_ctx* c, int kind, const trgl_uniforms* u, const double* clip,
     if (n > 0xffffffffull) return fail(c, TRGL_E_UNSUPPORTED, "trgl_draw: more than 2^32-1 triangles in one draw");
 
     const double* dclip = clip; const double* dvary = K ? vary : nullptr; const uint32_t* dcol = colors;
+    struct Hold { trgl_ctx* c; Hold(trgl_ctx* x) : c(x) { ++c->stage_hold; } ~Hold() { --c->stage_hold; } } hold(c);
     if (mem_kind == TRGL_MEM_HOST) {
         void* p = nullptr; int r;
         if ((r = stage_copy(c, clip, n * 12 * sizeof(double), &p))) return r;
@@ -293,6 +300,79 @@ int trgl_draw(trgl_ctx* c, int kind, const trgl_uniforms* u, const double* clip,
         c->queued_tris += m;
         done += m;
     }
+    return TRGL_OK;
+}
+
+int trgl_draw_indexed(trgl_ctx* c, int kind, const trgl_uniforms* u, const double projection[16], const double* vertices,
+                      int stride, uint64_t n_vertices, const uint32_t* indices, uint64_t n_faces, int mem_kind) {
+    CHKCTX(c);
+    if (kind != TRGL_SHADER_PHONG && kind != TRGL_SHADER_EYE) return fail(c, TRGL_E_INVALID, "trgl_draw_indexed: kind must be PHONG or EYE");
+    if (!u || !projection || !vertices || !indices) return fail(c, TRGL_E_INVALID, "trgl_draw_indexed: null argument");
+    if (stride < 8) return fail(c, TRGL_E_INVALID, "trgl_draw_indexed: vertex stride must be >= 8 doubles (pos3, normal3, uv2)");
+    if (mem_kind != TRGL_MEM_HOST && mem_kind != TRGL_MEM_DEVICE) return fail(c, TRGL_E_INVALID, "trgl_draw_indexed: bad mem_kind");
+    if (n_faces == 0) return TRGL_OK;
+    if (n_faces > 0xffffffffull / 3) return fail(c, TRGL_E_UNSUPPORTED, "trgl_draw_indexed: too many faces in one call");
+    const double* dv = vertices; const uint32_t* di = indices;
+    void* p = nullptr; int r;
+    struct Hold { trgl_ctx* c; Hold(trgl_ctx* x) : c(x) { ++c->stage_hold; } ~Hold() { --c->stage_hold; } } hold(c);
+    if (mem_kind == TRGL_MEM_HOST) {
+        for (uint64_t k = 0; k < 3 * n_faces; ++k)
+            if (indices[k] >= n_vertices) return fail(c, TRGL_E_INVALID, "trgl_draw_indexed: index out of range");
+        if ((r = stage_copy(c, vertices, n_vertices * (size_t)stride * sizeof(double), &p))) return r;
+        dv = (const double*)p;
+        if ((r = stage_copy(c, indices, 3 * n_faces * sizeof(uint32_t), &p))) return r;
+        di = (const uint32_t*)p;
+    }
+    double* clip = nullptr; double* vary = nullptr;
+    if ((r = stage_alloc(c, n_faces * 12 * sizeof(double), &p))) return r;
+    clip = (double*)p;
+    if ((r = stage_alloc(c, n_faces * 24 * sizeof(double), &p))) return r;
+    vary = (double*)p;
+    launch_vertex_stage(c->stream, u->model_view, projection, dv, stride, di, (uint32_t)n_faces, clip, vary);
+    HIPCHK(c, hipGetLastError());
+    return trgl_draw(c, kind, u, clip, vary, nullptr, n_faces, TRGL_MEM_DEVICE);
+}
+
+void trgl_ssao_defaults(trgl_ssao_params* p) {      // main.cpp:317-321
+    if (!p) return;
+    p->num_directions = 8; p->steps_per_direction = 8; p->sample_radius = 16.0; p->occlusion_threshold = 1e-3; p->intensity = 0.35;
+}
+
+static int flush_sync(trgl_ctx* c);
+
+int trgl_postprocess(trgl_ctx* c, const trgl_ssao_params* params, uint8_t* zimg, uint8_t* ao, uint8_t* fin) {
+    CHKCTX(c);
+    trgl_ssao_params sp; trgl_ssao_defaults(&sp);
+    if (params) sp = *params;
+    if (sp.num_directions < 1 || sp.num_directions > 16 || sp.steps_per_direction < 1)
+        return fail(c, TRGL_E_INVALID, "trgl_postprocess: 1..16 directions, >= 1 step");
+    int r = flush_sync(c); if (r) return r;
+    const size_t npx = (size_t)c->W * c->H;
+    uint8_t* d_out = nullptr; unsigned long long* d_keys = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_out, npx * 3 * 3));
+    HIPCHK(c, hipMalloc((void**)&d_keys, 16));
+    uint8_t* d_z = d_out; uint8_t* d_ao = d_out + npx * 3; uint8_t* d_fin = d_out + npx * 6;
+    hipStream_t s = c->stream;
+    if (zimg) launch_zimage(s, c->zb, c->W, c->H, d_keys, d_z);
+    if (ao || fin) {
+        double dx[16], dy[16];
+        for (int d = 0; d < sp.num_directions; ++d) {         // main.cpp:333-334, host libm as in the reference
+            double angle = 2.0 * 3.14159265358979323846 * d / sp.num_directions;
+            dx[d] = std::cos(angle); dy[d] = std::sin(angle);
+        }
+        launch_ssao(s, c->zb, c->W, c->H, dx, dy, sp.num_directions, sp.steps_per_direction, sp.sample_radius,
+                    sp.occlusion_threshold, sp.intensity, d_ao);
+    }
+    if (fin) {
+        if (c->bpp < 3) { (void)hipFree(d_out); (void)hipFree(d_keys); return fail(c, TRGL_E_UNSUPPORTED, "trgl_postprocess: composite needs an RGB(A) framebuffer"); }
+        launch_composite(s, c->fb, c->bpp, d_ao, c->W, c->H, d_fin);
+    }
+    HIPCHK(c, hipGetLastError());
+    if (zimg) HIPCHK(c, hipMemcpyAsync(zimg, d_z, npx * 3, hipMemcpyDeviceToHost, s));
+    if (ao) HIPCHK(c, hipMemcpyAsync(ao, d_ao, npx * 3, hipMemcpyDeviceToHost, s));
+    if (fin) HIPCHK(c, hipMemcpyAsync(fin, d_fin, npx * 3, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipFree(d_out)); HIPCHK(c, hipFree(d_keys));
     return TRGL_OK;
 }
 
@@ -411,9 +491,10 @@ int trgl_flush(trgl_ctx* c) {
     for (auto& ch : c->stage) if (ch.used) had_stage = true;
     c->draws.clear();
     c->queued_tris = 0;
-    if (had_stage) {                       // staged host data may be recycled only once the kernels are done
+    if (had_stage) {                       // staged data may be recycled only once the kernels are done ...
         HIPCHK(c, hipStreamSynchronize(s));
-        for (auto& ch : c->stage) ch.used = 0;
+        if (!c->stage_hold)                // ... and not while a draw call in progress still owns staged arrays
+            for (auto& ch : c->stage) ch.used = 0;
     }
     return TRGL_OK;
 }
