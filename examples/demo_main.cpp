@@ -1,12 +1,13 @@
 // demo_main.cpp — a main.cpp-shaped caller (the reference's render section, main.cpp:606-792) on the MI355X
 // rasterizer through the shim headers: same globals, same face loops, same rasterize() calls.
-//   demo_main <model.bin> <out.bin> [out.tga]
+//   demo_main <model.bin> <out.bin> [out.tga [postprocess_basename]]
 // model.bin is written by tests/test_shim_demo.py (a procedural head stand-in: the reference's obj/ assets are
 // absent); out.bin = framebuffer bytes, z-buffer, stats line — compared with the CPU oracle by the test.
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <string>
 #include <vector>
 
 #include "../tinyrenderder_amd/shim/trgl_shaders.h"
@@ -109,6 +110,14 @@ int main(int argc, char** argv) {
     }
     gl_flush(framebuffer);
     if (argc > 3) framebuffer.write_tga_file(argv[3]);       // main.cpp:743
+    if (argc > 4) {                                          // main.cpp:751-785: zbuffer.tga, ao.tga, final.tga
+        TGAImage zimg, ao_map, final_result;
+        gl_postprocess(framebuffer, &zimg, &ao_map, &final_result);
+        const std::string base = argv[4];
+        zimg.write_tga_file(base + "_zbuffer.tga");
+        ao_map.write_tga_file(base + "_ao.tga");
+        final_result.write_tga_file(base + "_final.tga");
+    }
 
     // stats line exactly as print_render_stats() prints it (our_gl.cpp:204-210), captured for the test
     trgl_stats st{};

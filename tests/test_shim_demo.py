@@ -45,7 +45,8 @@ def test_main_cpp_shaped_demo_matches_oracle(tmp_path):
     fclip, fcol = scenes.random_triangles(300, W, H, seed=8, rmin=2, rmax=20)
     model, out, tga = tmp_path / "model.bin", tmp_path / "out.bin", tmp_path / "out.tga"
     _write_model(model, W, H, bpp, hd, 0.75, (d, n, s), fclip, fcol)
-    r = subprocess.run([DEMO, str(model), str(out), str(tga)], capture_output=True, text=True)
+    post = str(tmp_path / "post")
+    r = subprocess.run([DEMO, str(model), str(out), str(tga), post], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     raw = open(out, "rb").read()
     fb = np.frombuffer(raw, np.uint8, W * H * bpp).reshape(H, W, bpp)
@@ -67,3 +68,8 @@ def test_main_cpp_shaped_demo_matches_oracle(tmp_path):
     assert line == orc.format_stats_line(o.stats)
     assert r.stderr.strip().endswith(line)                # print_render_stats() wrote the same line to stderr
     assert open(tga, "rb").read() == orc.tga_encode(fb)   # the written file is what the reference writer would emit
+    # main.cpp:751-785: zbuffer.tga / ao.tga / final.tga from the device post-process, byte for byte
+    ao = orc.ssao(z)
+    assert open(post + "_zbuffer.tga", "rb").read() == orc.tga_encode(orc.zbuffer_image(z))
+    assert open(post + "_ao.tga", "rb").read() == orc.tga_encode(ao)
+    assert open(post + "_final.tga", "rb").read() == orc.tga_encode(orc.composite(fb, ao))

@@ -196,6 +196,21 @@ inline void gl_flush(TGAImage& framebuffer) {
     TRGL_SHIM_CHK(trgl_read_zbuffer(s.ctx, zbuffer.data()));
 }
 
+// main.cpp:751-785 on the device (z-buffer never leaves HBM): fills the three images the reference writes as
+// zbuffer.tga, ao.tga and final.tga.  Any of the pointers may be null.
+inline void gl_postprocess(TGAImage& framebuffer, TGAImage* zbuffer_image, TGAImage* ao_map, TGAImage* final_result) {
+    using namespace trgl_shim;
+    State& s = state();
+    bind(framebuffer);
+    submit_batch();
+    auto prep = [&](TGAImage* img) -> std::uint8_t* {
+        if (!img) return nullptr;
+        if (img->width() != s.w || img->height() != s.h || img->bytespp() != 3) *img = TGAImage(s.w, s.h, TGAImage::RGB);
+        return img->buffer();
+    };
+    TRGL_SHIM_CHK(trgl_postprocess(s.ctx, nullptr, prep(zbuffer_image), prep(ao_map), prep(final_result)));
+}
+
 inline void print_render_stats() {                                                // our_gl.cpp:204-210
     trgl_shim::State& s = trgl_shim::state();
     trgl_stats st{};
