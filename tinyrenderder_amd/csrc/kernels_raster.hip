@@ -316,6 +316,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                                                 unsigned long long* __restrict__ item_stats) {
     __shared__ __attribute__((aligned(16))) double   s_z[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
     __shared__ __attribute__((aligned(16))) uint32_t s_c[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
+    __shared__ double s_hz[TRGL_WAVES_PER_BLOCK][64];    // per-cell depth maxima for the hierarchical-Z test
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
 #pragma unroll
         for (int k = 0; k < 8; ++k) cur.q[k] = make_uint4(0, 0, 0, 0);
     }
+    double* hz = s_hz[w];
     for (uint32_t bs = beg; bs < end; bs += 64) {
         const uint32_t nbatch = min(64u, end - bs);
         RecQ nxt = cur;
@@ -392,7 +394,51 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
             uint32_t p = bs + 64 + lane;
             nxt = load_rec(recs, vals[p < end ? p : end - 1], true);
         }
-        for (uint32_t j = 0; j < nbatch; ++j) {
+        // ---- hierarchical Z, once per batch of 64 list entries -------------------------------------------------
+        // Lane l owns the 4x4-pixel cell (l&7, l>>3) of the tile and publishes the maximum depth currently stored
+        // in it.  Then every lane tests ITS OWN triangle of the batch: for a well-scaled triangle each covered
+        // pixel has b_i >= 0 and b0+b1+b2 = 1 +- 2^-50, so the interpolated depth (our_gl.cpp:156-158) is
+        //   z >= min(z0,z1,z2) - 2^-49 * max|z_i|      (rounding included; the margin below is 2^-40),
+        // and the z-test is a strict `<` (our_gl.cpp:165): if that bound is >= the maximum of every cell its bbox
+        // touches, no pixel can pass and the triangle is skipped before its constants are even broadcast.
+        // Cell maxima only fall while a batch is rasterized, so values from the batch start stay valid bounds.
+        {
+            const int cx = lane & 7, cy = lane >> 3;
+            double m = -__builtin_inf();
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 4; ++dx) m = dmax(m, zt[lds_index(4 * cx + dx, 4 * cy + dy)]);
+            hz[lane] = m;
+            __builtin_amdgcn_wave_barrier();
+        }
+        unsigned long long todo;
+        {
+            const int bx0 = (int)(cur.q[7].x & 0xffff), by0 = (int)(cur.q[7].x >> 16);
+            const int bx1 = (int)(cur.q[7].y & 0xffff), by1 = (int)(cur.q[7].y >> 16);
+            const int x0 = max(bx0, px0), x1 = min(bx1, xa1), y0 = max(by0, ya0), y1 = min(by1, ya1);
+            bool skip = (uint32_t)lane >= nbatch || x0 > x1 || y0 > y1;      // not in the list / misses this band
+            const double ruz_l = __hiloint2double((int)cur.q[3].w, (int)cur.q[3].z);
+            if (!skip && ruz_l != 0.0) {
+                const double z0 = __hiloint2double((int)cur.q[4].y, (int)cur.q[4].x);
+                const double z1 = __hiloint2double((int)cur.q[4].w, (int)cur.q[4].z);
+                const double z2 = __hiloint2double((int)cur.q[5].y, (int)cur.q[5].x);
+                const double zlo = dmin(dmin(z0, z1), z2), zabs = dmax(dmax(fabs(z0), fabs(z1)), fabs(z2));
+                const double zbound = zlo - zabs * 0x1p-40;
+                const int cx0 = (x0 & 31) >> 2, cx1 = (x1 & 31) >> 2, cy0 = (y0 & 31) >> 2, cy1 = (y1 & 31) >> 2;
+                if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= 16) {
+                    bool behind = true;
+                    for (int cyy = cy0; cyy <= cy1 && behind; ++cyy)
+                        for (int cxx = cx0; cxx <= cx1; ++cxx)
+                            if (!(zbound >= hz[cyy * 8 + cxx])) { behind = false; break; }
+                    skip = behind;
+                }
+            }
+            todo = __ballot(!skip);
+        }
+        while (todo) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(todo);          // list order = ascending lane
+            todo &= todo - 1;
             TriConst T;
             T.ax = bcast_d(cur.q[0].x, cur.q[0].y, j); T.ay = bcast_d(cur.q[0].z, cur.q[0].w, j);
             T.s0x = bcast_d(cur.q[1].x, cur.q[1].y, j); T.s0y = bcast_d(cur.q[1].z, cur.q[1].w, j);
