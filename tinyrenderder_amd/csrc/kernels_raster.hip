@@ -214,6 +214,7 @@ __device__ __forceinline__ double div_by_uz(double a, double uz, double ruz) {
 // Per-triangle constants of the pixel loop (wave-uniform: they live in SGPRs).
 struct TriConst {
     double ax, ay, s0x, s0y, s1x, s1y, uz, ruz, z0, z1, z2, iw0, iw1, iw2;
+    double zbound;      // lower bound of the depth of any covered pixel (-inf if the triangle is not well scaled)
     uint32_t bb0, bb1, color, dl, tri;
 };
 // Per-wave tile state.
@@ -257,14 +258,18 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, TileState& S,
                 cov = act && !(b0 < 0 || b1 < 0 || b2 < 0);                   // :152
             }
             if (cov) {
+                const int li = lds_index(x, y);
+                const double zold = S.zt[li];
+                // early z, exact: every covered pixel of this triangle has z >= T.zbound (see the hierarchical-Z
+                // comment in k_raster) and the test is a strict `<`, so a pixel with zbound >= zold cannot pass;
+                // when no covered lane is left the whole division / depth phase is skipped
+                if (!WELL_SCALED || T.zbound < zold) {
                 if (WELL_SCALED) {
                     b0 = 1.0 - div_by_uz(us, uz, ruz);
                     b1 = div_by_uz(uy, uz, ruz);
                     b2 = div_by_uz(ux, uz, ruz);
                 }
                 const double z = b0 * T.z0 + b1 * T.z1 + b2 * T.z2;           // :156-158
-                const int li = lds_index(x, y);
-                const double zold = S.zt[li];
                 // :160 — on the well-scaled path b0..b2 and the NDC depths are finite and bounded, so z is finite
                 if ((WELL_SCALED || __builtin_isfinite(z)) && (z < zold)) {   // :165
                     uint32_t color;
@@ -299,6 +304,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, TileState& S,
                             atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
                         }
                     }
+                }
                 }
             }
         }
@@ -413,6 +419,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
             __builtin_amdgcn_wave_barrier();
         }
         unsigned long long todo;
+        double zbound_l = -__builtin_inf();       // this lane's triangle: lower bound of its covered depths
         {
             const int bx0 = (int)(cur.q[7].x & 0xffff), by0 = (int)(cur.q[7].x >> 16);
             const int bx1 = (int)(cur.q[7].y & 0xffff), by1 = (int)(cur.q[7].y >> 16);
@@ -425,6 +432,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                 const double z2 = __hiloint2double((int)cur.q[5].y, (int)cur.q[5].x);
                 const double zlo = dmin(dmin(z0, z1), z2), zabs = dmax(dmax(fabs(z0), fabs(z1)), fabs(z2));
                 const double zbound = zlo - zabs * 0x1p-40;
+                zbound_l = zbound;
                 const int cx0 = (x0 & 31) >> 2, cx1 = (x1 & 31) >> 2, cy0 = (y0 & 31) >> 2, cy1 = (y1 & 31) >> 2;
                 if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= 16) {
                     bool behind = true;
@@ -452,6 +460,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
             }
             T.bb0 = bcast_u(cur.q[7].x, j); T.bb1 = bcast_u(cur.q[7].y, j); T.color = bcast_u(cur.q[7].z, j);
             T.tri = bcast_u(cur.tri, j);
+            T.zbound = bcast_d((uint32_t)__double2loint(zbound_l), (uint32_t)__double2hiint(zbound_l), j);
             if (T.ruz != 0.0) raster_triangle<FLAT_ONLY, true>(T, S, draws, tex, stats);    // wave-uniform
             else raster_triangle<FLAT_ONLY, false>(T, S, draws, tex, stats);
         }
