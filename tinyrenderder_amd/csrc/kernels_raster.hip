@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                                                 unsigned long long* __restrict__ item_stats) {
     __shared__ __attribute__((aligned(16))) double   s_z[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
     __shared__ __attribute__((aligned(16))) uint32_t s_c[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
-    __shared__ double s_hz[TRGL_WAVES_PER_BLOCK][64];    // per-cell depth maxima for the hierarchical-Z test
+    __shared__ double s_hz[TRGL_WAVES_PER_BLOCK][80];    // depth maxima of the 64 4x4-pixel cells + 16 8x8-pixel cells
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -417,6 +417,12 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                 for (int dx = 0; dx < 4; ++dx) m = dmax(m, zt[lds_index(4 * cx + dx, 4 * cy + dy)]);
             hz[lane] = m;
             __builtin_amdgcn_wave_barrier();
+            // coarse level: 8x8-pixel cells (4x4 of them), for triangles whose bbox spans more than 16 fine cells
+            if (lane < 16) {
+                const int f = (lane >> 2) * 16 + (lane & 3) * 2;
+                hz[64 + lane] = dmax(dmax(hz[f], hz[f + 1]), dmax(hz[f + 8], hz[f + 9]));
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         unsigned long long todo;
         double zbound_l = -__builtin_inf();       // this lane's triangle: lower bound of its covered depths
@@ -434,13 +440,17 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                 const double zbound = zlo - zabs * 0x1p-40;
                 zbound_l = zbound;
                 const int cx0 = (x0 & 31) >> 2, cx1 = (x1 & 31) >> 2, cy0 = (y0 & 31) >> 2, cy1 = (y1 & 31) >> 2;
+                bool behind = true;
                 if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= 16) {
-                    bool behind = true;
                     for (int cyy = cy0; cyy <= cy1 && behind; ++cyy)
                         for (int cxx = cx0; cxx <= cx1; ++cxx)
                             if (!(zbound >= hz[cyy * 8 + cxx])) { behind = false; break; }
-                    skip = behind;
+                } else {
+                    for (int cyy = cy0 >> 1; cyy <= (cy1 >> 1) && behind; ++cyy)
+                        for (int cxx = cx0 >> 1; cxx <= (cx1 >> 1); ++cxx)
+                            if (!(zbound >= hz[64 + cyy * 4 + cxx])) { behind = false; break; }
                 }
+                skip = behind;
             }
             todo = __ballot(!skip);
         }
