@@ -49,6 +49,7 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
                                                          TriRec* __restrict__ recs, uint32_t* __restrict__ cnt,
                                                          uint2* __restrict__ tilebox, DevStats* __restrict__ stats) {
     __shared__ __attribute__((aligned(16))) double s_buf[SETUP_THREADS * 16];    // 32 KB: in [256][12], then out [256][16]
+    __shared__ uint8_t s_keep[SETUP_THREADS];
     const DrawDesc& d = draws[draw_idx];
     const uint32_t b0 = blockIdx.x * SETUP_THREADS;
     const uint32_t nb = min((uint32_t)SETUP_THREADS, d.n - b0);
@@ -153,11 +154,14 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
         const uint4* r4 = reinterpret_cast<const uint4*>(&r);
 #pragma unroll
         for (int c = 0; c < 8; ++c) l4[tid * 8 + (c ^ (tid & 7))] = r4[c];
+        s_keep[tid] = ntiles != 0;
         __syncthreads();
+        // a record is only ever read through a (tile, triangle) pair: triangles without pairs (rejected, or
+        // outside this context's strip — 7 of 8 on an 8-GPU shard) need no 128-B store
         uint4* dst = reinterpret_cast<uint4*>(recs + d.first + b0);
         for (uint32_t k = tid; k < nb * 8; k += SETUP_THREADS) {
             uint32_t t = k >> 3, c = k & 7;
-            dst[k] = l4[t * 8 + (c ^ (t & 7))];
+            if (s_keep[t]) dst[k] = l4[t * 8 + (c ^ (t & 7))];
         }
     }
     // bbox stats (our_gl.cpp:138-141): one set of atomics per wave
