@@ -473,21 +473,9 @@ int trgl_flush(trgl_ctx* c) {
     // A lone wave needs ~1-3 us per list entry (one long dependent fp64 chain); throughput comes from many waves.
     // So lists longer than twice the mean list length (at least 8 entries) are cut into 2..16 row bands: dense
     // uniform scenes (C4: 1100 entries in every tile) never split, sparse or uneven ones (meshes) get parallelism.
-    // When the context owns fewer tiles than the chip has wave slots (a strip of a multi-GPU frame, a small image),
-    // every tile is cut into bands as well: band-missing triangles are dropped by the per-lane test at batch
-    // level, so extra bands cost little and fill the machine.
     const uint64_t strip_tiles = (uint64_t)(fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x;
     uint32_t split_len = 8;
-    if (strip_tiles) {
-        uint64_t mean = (uint64_t)P / strip_tiles, thr = 2 * mean;
-        const uint64_t target_items = 8192;                 // ~2.7 waves per SIMD on 256 CUs
-        if (strip_tiles < target_items && mean >= 64) {
-            uint64_t f = (target_items + strip_tiles - 1) / strip_tiles;      // bands wanted per tile
-            if (f > 16) f = 16;
-            thr = mean / f;                                                    // a list of `mean` entries then makes >= f bands
-        }
-        if (thr > split_len) split_len = (uint32_t)thr;
-    }
+    if (strip_tiles && 2 * (uint64_t)P / strip_tiles > split_len) split_len = (uint32_t)(2 * (uint64_t)P / strip_tiles);
     const uint32_t max_items = raster_max_items(fp, P, split_len);
     if ((r = grow(c, c->items, c->cap_items, (size_t)max_items + 64))) return r;
     if ((r = grow(c, c->item_stats, c->cap_item_stats, ((size_t)max_items + 64) * 4))) return r;
