@@ -1,0 +1,16 @@
+"""k_raster work counters on the C4 frame (diagnostic build: make -C tinyrenderder_amd/csrc ../libtrgl_dbg.so)."""
+import ctypes as C, sys
+sys.path.insert(0, '.')
+import numpy as np, torch
+from tinyrenderder_amd import scenes
+W = H = 4096; N = 10_000_000
+clip, col = scenes.random_triangles(N, W, H)
+L = C.CDLL('tinyrenderder_amd/libtrgl_dbg.so')
+h = C.c_void_p(); assert L.trgl_create(0, W, H, 3, C.byref(h)) == 0
+dclip = torch.from_numpy(clip).cuda(); dcol = torch.from_numpy(col.view(np.int32)).cuda()
+L.trgl_draw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+assert L.trgl_draw(h, 0, None, dclip.data_ptr(), None, dcol.data_ptr(), N, 1) == 0
+out = (C.c_ulonglong * 8)(); L.trgl_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+assert L.trgl_debug_counters(h, out) == 0
+names = ["entries rasterized", "blocks in coverage test", "blocks with coverage", "blocks reaching divisions", "list entries (pairs)"]
+for n, v in zip(names, out): print(f"{n:28s} {v:>12d}  per triangle {v / N:.3f}")

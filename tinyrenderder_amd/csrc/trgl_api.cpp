@@ -102,6 +102,7 @@ static int reset_dev_stats(trgl_ctx* c) {
     s.pairs_total = 0;
     s.zero_pos_key = s.zero_neg_key = TRGL_ZERO_KEY_EMPTY;
     s.zero_locked = 0; s.zero_sign = 0;
+    for (int k = 0; k < 8; ++k) s.dbg[k] = 0;
     *c->stats_pinned = s;
     HIPCHK(c, hipMemcpyAsync(c->stats_dev, c->stats_pinned, sizeof(DevStats), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -641,6 +642,15 @@ int trgl_reset_phase_ms(trgl_ctx* c) {
     c->flushes_timed = 0;
     return TRGL_OK;
 }
+// diagnostic builds (-DTRGL_DEBUG_COUNTERS): k_raster work counters since the last stats reset
+extern "C" int trgl_debug_counters(trgl_ctx* c, unsigned long long out[8]) {
+    CHKCTX(c);
+    int r = flush_sync(c); if (r) return r;
+    HIPCHK(c, hipMemcpy(c->stats_pinned, c->stats_dev, sizeof(DevStats), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; ++k) out[k] = c->stats_pinned->dbg[k];
+    return TRGL_OK;
+}
+
 int trgl_get_last_flush_info(trgl_ctx* c, uint64_t* triangles, uint64_t* pairs, uint64_t* tiles) {
     if (!c) return TRGL_E_INVALID;
     if (triangles) *triangles = c->last_tris;
