@@ -215,7 +215,6 @@ __device__ __forceinline__ double div_by_uz(double a, double uz, double ruz) {
 struct TriConst {
     double ax, ay, s0x, s0y, s1x, s1y, uz, ruz, z0, z1, z2, iw0, iw1, iw2;
     double zbound;      // lower bound of the depth of any covered pixel (-inf if the triangle is not well scaled)
-    uint32_t dead;      // bit k: the k-th 8x8 block of the scan (row-major from the clamped bbox corner) cannot pass
     uint32_t bb0, bb1, color, dl, tri;
 };
 // Per-wave tile state.
@@ -243,12 +242,8 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, TileState& S,
     const double uz = T.uz, ruz = T.ruz;
     const int x0 = max((int)(T.bb0 & 0xffff), S.px0), x1 = min((int)(T.bb1 & 0xffff), S.xa1);
     const int y0 = max((int)(T.bb0 >> 16), S.ya0), y1 = min((int)(T.bb1 >> 16), S.ya1);
-    uint32_t dead = T.dead;
     for (int by = y0; by <= y1; by += 8) {
         for (int bx = x0; bx <= x1; bx += 8) {
-            const bool is_dead = dead & 1u;       // hierarchical Z decided at batch level (k_raster): nothing can pass here
-            dead >>= 1;
-            if (is_dead) continue;
             const int x = bx + (lane & 7), y = by + (lane >> 3);
             const bool act = (x <= x1) && (y <= y1);
             TRGL_DBG(1, 1);                                                    // blocks entering the coverage test
@@ -338,7 +333,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                                                 unsigned long long* __restrict__ item_stats) {
     __shared__ __attribute__((aligned(16))) double   s_z[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
     __shared__ __attribute__((aligned(16))) uint32_t s_c[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
-    __shared__ double s_hz[TRGL_WAVES_PER_BLOCK][64];    // depth maxima of the tile's 64 4x4-pixel cells (hierarchical Z)
+    __shared__ double s_hz[TRGL_WAVES_PER_BLOCK][80];    // depth maxima of the 64 4x4-pixel cells + 16 8x8-pixel cells
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -425,10 +420,10 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
         // pixel has b_i >= 0 and b0+b1+b2 = 1 +- 2^-50, so the interpolated depth (our_gl.cpp:156-158) is
         //   z >= min(z0,z1,z2) - 2^-49 * max|z_i|      (rounding included; the margin below is 2^-40),
         // and the z-test is a strict `<` (our_gl.cpp:165): if that bound is >= the maximum of every cell its bbox
-        // touches, no pixel can pass.  The test is made per 8x8 block of the triangle's scan: dead blocks cost two
-        // scalar instructions in raster_triangle, and a triangle whose blocks are all dead is skipped before its
-        // constants are even broadcast.  Cell maxima only fall while a batch is rasterized, so the values from the
-        // batch start stay valid upper bounds.
+        // touches, no pixel can pass and the triangle is skipped before its constants are even broadcast.
+        // Cell maxima only fall while a batch is rasterized, so values from the batch start stay valid bounds.
+        // (Finer variants lost: a dead-block mask per triangle skipped only 10 % more blocks — triangles that
+        // survive have a low bound, so their blocks are rarely dead — and its per-lane loop cost 0.5 ms.)
         {
             const int cx = lane & 7, cy = lane >> 3;
             double m = -__builtin_inf();
@@ -438,10 +433,15 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                 for (int dx = 0; dx < 4; ++dx) m = dmax(m, zt[lds_index(4 * cx + dx, 4 * cy + dy)]);
             hz[lane] = m;
             __builtin_amdgcn_wave_barrier();
+            // coarse level: 8x8-pixel cells (4x4 of them), for triangles whose bbox spans more than 16 fine cells
+            if (lane < 16) {
+                const int f = (lane >> 2) * 16 + (lane & 3) * 2;
+                hz[64 + lane] = dmax(dmax(hz[f], hz[f + 1]), dmax(hz[f + 8], hz[f + 9]));
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         unsigned long long todo;
         double zbound_l = -__builtin_inf();       // this lane's triangle: lower bound of its covered depths
-        uint32_t dead_l = 0;                      // ... and which of its 8x8 blocks are provably behind what is stored
         {
             const int bx0 = (int)(cur.q[7].x & 0xffff), by0 = (int)(cur.q[7].x >> 16);
             const int bx1 = (int)(cur.q[7].y & 0xffff), by1 = (int)(cur.q[7].y >> 16);
@@ -455,23 +455,18 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                 const double zlo = dmin(dmin(z0, z1), z2), zabs = dmax(dmax(fabs(z0), fabs(z1)), fabs(z2));
                 const double zbound = zlo - zabs * 0x1p-40;
                 zbound_l = zbound;
-                // block k of the scan (rows of 8x8 blocks from the clamped bbox corner, at most 4x4 of them) is dead
-                // when the bound is >= the maximum of every 4x4-pixel cell it touches (at most 3x3 cells)
-                uint32_t dmask = 0, k = 0;
-                bool all_dead = true;
-                for (int by = y0; by <= y1; by += 8) {
-                    const int c_y0 = (by & 31) >> 2, c_y1 = (min(by + 7, y1) & 31) >> 2;
-                    for (int bx = x0; bx <= x1; bx += 8, ++k) {
-                        const int c_x0 = (bx & 31) >> 2, c_x1 = (min(bx + 7, x1) & 31) >> 2;
-                        bool behind = true;
-                        for (int cyy = c_y0; cyy <= c_y1 && behind; ++cyy)
-                            for (int cxx = c_x0; cxx <= c_x1; ++cxx)
-                                if (!(zbound >= hz[cyy * 8 + cxx])) { behind = false; break; }
-                        if (behind) dmask |= 1u << k; else all_dead = false;
-                    }
+                const int cx0 = (x0 & 31) >> 2, cx1 = (x1 & 31) >> 2, cy0 = (y0 & 31) >> 2, cy1 = (y1 & 31) >> 2;
+                bool behind = true;
+                if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= 16) {
+                    for (int cyy = cy0; cyy <= cy1 && behind; ++cyy)
+                        for (int cxx = cx0; cxx <= cx1; ++cxx)
+                            if (!(zbound >= hz[cyy * 8 + cxx])) { behind = false; break; }
+                } else {
+                    for (int cyy = cy0 >> 1; cyy <= (cy1 >> 1) && behind; ++cyy)
+                        for (int cxx = cx0 >> 1; cxx <= (cx1 >> 1); ++cxx)
+                            if (!(zbound >= hz[64 + cyy * 4 + cxx])) { behind = false; break; }
                 }
-                dead_l = dmask;
-                skip = all_dead;
+                skip = behind;
             }
             todo = __ballot(!skip);
         }
@@ -492,7 +487,6 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
             T.bb0 = bcast_u(cur.q[7].x, j); T.bb1 = bcast_u(cur.q[7].y, j); T.color = bcast_u(cur.q[7].z, j);
             T.tri = bcast_u(cur.tri, j);
             T.zbound = bcast_d((uint32_t)__double2loint(zbound_l), (uint32_t)__double2hiint(zbound_l), j);
-            T.dead = bcast_u(dead_l, j);
             TRGL_DBG(0, 1);                                                    // list entries rasterized (not skipped)
             if (T.ruz != 0.0) raster_triangle<FLAT_ONLY, true>(T, S, draws, tex, stats);    // wave-uniform
             else raster_triangle<FLAT_ONLY, false>(T, S, draws, tex, stats);
