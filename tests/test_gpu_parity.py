@@ -214,3 +214,42 @@ def test_baseline_phong_configs_full_size(cfg):
     assert np.array_equal(fb, o.fb)
     assert st == o.stats
     assert st[1] > 100_000          # the head covers a good part of the screen
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_flat_scenes_against_oracle(seed):
+    """Randomised scenes for the depth shortcuts (hierarchical Z, early z, sign coverage, FMA division): dense
+    overdraw, perspective w, depths partly outside [-1,1], exact ties and duplicates, finite z clears, several
+    flushes onto the same tiles, odd image sizes, strips."""
+    rng = scenes.SplitMix64(1000 + seed)
+    u = rng.uniform(16)
+    W = int(64 + u[0] * 300); H = int(64 + u[1] * 300)
+    if seed % 3 == 0:
+        W, H = (W // 4) * 4, (H // 2) * 2
+    n = int(2000 + u[2] * 30000)
+    clip, col = scenes.random_triangles(n, W, H, seed=2000 + seed, rmin=1 + 3 * u[3], rmax=8 + 120 * u[4],
+                                        perspective_w=bool(seed & 1))
+    clip = clip.copy()
+    zs = 0.2 + 2.0 * u[5]                                  # stretch depths so some vertices leave [-1,1]
+    for v in range(3):
+        clip[:, 4 * v + 2] *= zs
+    k = n // 7
+    clip[k:2 * k] = clip[0:k]                              # exact duplicates: ties must keep the earlier triangle
+    clip[3 * k:4 * k, [2, 6, 10]] = np.round(clip[3 * k:4 * k, [2, 6, 10]] * 4) / 4 * clip[3 * k:4 * k, [3, 7, 11]]   # few distinct depths
+    zclear = np.inf if seed % 4 else float(0.3 * (u[6] - 0.5))
+    strip = None if seed % 5 else (H // 3, H - H // 5)
+    parts = 1 + seed % 3
+    with Context(W, H, 3) as ctx:
+        ctx.clear((9, 8, 7, 255), zclear)
+        if strip:
+            ctx.set_strip(*strip)
+        edges = [n * i // parts for i in range(parts + 1)]
+        for a, b in zip(edges[:-1], edges[1:]):
+            ctx.draw(FLAT, clip[a:b], colors=col[a:b]); ctx.flush()
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    o = orc.Oracle(W, H, 3, clear_bgra=(9, 8, 7, 255), z_clear=zclear, strip=strip)
+    o.draw(orc.FLAT, clip, colors=col)
+    rows = slice(None) if strip is None else slice(*strip)
+    assert np.array_equal(z[rows].view(np.uint64), o.z[rows].view(np.uint64))
+    assert np.array_equal(fb[rows], o.fb[rows])
+    assert st == o.stats
