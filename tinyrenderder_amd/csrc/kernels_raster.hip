@@ -236,11 +236,10 @@ struct TileState {
 // WELL_SCALED (see k_setup) selects the division-free coverage test and the FMA division by u.z; everything
 // after the coverage test sits under `if (cov)`, so a block with no covered pixel costs two scalar instructions.
 template <bool FLAT_ONLY, bool WELL_SCALED>
-__device__ __forceinline__ void raster_triangle(TriConst& T, const RecQ& cur, uint32_t j, TileState& S,
-                                                const DrawDesc* __restrict__ draws,
+__device__ __forceinline__ void raster_triangle(const TriConst& T, TileState& S, const DrawDesc* __restrict__ draws,
                                                 const DevTexture* __restrict__ tex, DevStats* __restrict__ stats) {
     const int lane = S.lane;
-    const double uz = T.uz;
+    const double uz = T.uz, ruz = T.ruz;
     const int x0 = max((int)(T.bb0 & 0xffff), S.px0), x1 = min((int)(T.bb1 & 0xffff), S.xa1);
     const int y0 = max((int)(T.bb0 >> 16), S.ya0), y1 = min((int)(T.bb1 >> 16), S.ya1);
     for (int by = y0; by <= y1; by += 8) {
@@ -276,13 +275,6 @@ __device__ __forceinline__ void raster_triangle(TriConst& T, const RecQ& cur, ui
                 // comment in k_raster) and the test is a strict `<`, so a pixel with zbound >= zold cannot pass;
                 // when no covered lane is left the whole division / depth phase is skipped
                 if (!WELL_SCALED || T.zbound < zold) {
-                // the constants only this (rarer) part needs are broadcast here, not once per list entry
-                if (WELL_SCALED) {
-                    T.ruz = bcast_d(cur.q[3].z, cur.q[3].w, j);
-                    T.z0 = bcast_d(cur.q[4].x, cur.q[4].y, j); T.z1 = bcast_d(cur.q[4].z, cur.q[4].w, j);
-                    T.z2 = bcast_d(cur.q[5].x, cur.q[5].y, j); T.color = bcast_u(cur.q[7].z, j);
-                }
-                const double ruz = T.ruz;
                 if (WELL_SCALED) {
                     b0 = 1.0 - div_by_uz(us, uz, ruz);
                     b1 = div_by_uz(uy, uz, ruz);
@@ -319,7 +311,7 @@ __device__ __forceinline__ void raster_triangle(TriConst& T, const RecQ& cur, ui
                     if ((z < S.zmin) || (S.zmax < z)) {
                         S.zmin = dmin(S.zmin, z); S.zmax = dmax(S.zmax, z);
                         if (z == 0.0 && !S.zero_locked) {
-                            unsigned long long order = ((unsigned long long)bcast_u(cur.tri, j) << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
+                            unsigned long long order = ((unsigned long long)T.tri << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
                             atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
                         }
                     }
@@ -482,24 +474,22 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
             const uint32_t j = (uint32_t)__builtin_ctzll(todo);          // list order = ascending lane
             todo &= todo - 1;
             TriConst T;
-            // hot constants (coverage test): 18 v_readlane; the rest is broadcast in raster_triangle when needed
             T.ax = bcast_d(cur.q[0].x, cur.q[0].y, j); T.ay = bcast_d(cur.q[0].z, cur.q[0].w, j);
             T.s0x = bcast_d(cur.q[1].x, cur.q[1].y, j); T.s0y = bcast_d(cur.q[1].z, cur.q[1].w, j);
             T.s1x = bcast_d(cur.q[2].x, cur.q[2].y, j); T.s1y = bcast_d(cur.q[2].z, cur.q[2].w, j);
-            T.uz = bcast_d(cur.q[3].x, cur.q[3].y, j);
-            T.bb0 = bcast_u(cur.q[7].x, j); T.bb1 = bcast_u(cur.q[7].y, j);
-            T.zbound = bcast_d((uint32_t)__double2loint(zbound_l), (uint32_t)__double2hiint(zbound_l), j);
-            const bool well_scaled = T.zbound != -__builtin_inf();      // k_setup's flag (ruz != 0), via the bound
-            if (!FLAT_ONLY || !well_scaled) {
-                T.ruz = bcast_d(cur.q[3].z, cur.q[3].w, j);
-                T.z0 = bcast_d(cur.q[4].x, cur.q[4].y, j); T.z1 = bcast_d(cur.q[4].z, cur.q[4].w, j);
-                T.z2 = bcast_d(cur.q[5].x, cur.q[5].y, j); T.color = bcast_u(cur.q[7].z, j);
+            T.uz = bcast_d(cur.q[3].x, cur.q[3].y, j); T.ruz = bcast_d(cur.q[3].z, cur.q[3].w, j);
+            T.z0 = bcast_d(cur.q[4].x, cur.q[4].y, j); T.z1 = bcast_d(cur.q[4].z, cur.q[4].w, j);
+            T.z2 = bcast_d(cur.q[5].x, cur.q[5].y, j);
+            if (!FLAT_ONLY) {
                 T.iw0 = bcast_d(cur.q[5].z, cur.q[5].w, j); T.iw1 = bcast_d(cur.q[6].x, cur.q[6].y, j);
                 T.iw2 = bcast_d(cur.q[6].z, cur.q[6].w, j); T.dl = bcast_u(cur.q[7].w, j);
             }
+            T.bb0 = bcast_u(cur.q[7].x, j); T.bb1 = bcast_u(cur.q[7].y, j); T.color = bcast_u(cur.q[7].z, j);
+            T.tri = bcast_u(cur.tri, j);
+            T.zbound = bcast_d((uint32_t)__double2loint(zbound_l), (uint32_t)__double2hiint(zbound_l), j);
             TRGL_DBG(0, 1);                                                    // list entries rasterized (not skipped)
-            if (well_scaled) raster_triangle<FLAT_ONLY, true>(T, cur, j, S, draws, tex, stats);    // wave-uniform
-            else raster_triangle<FLAT_ONLY, false>(T, cur, j, S, draws, tex, stats);
+            if (T.ruz != 0.0) raster_triangle<FLAT_ONLY, true>(T, S, draws, tex, stats);    // wave-uniform
+            else raster_triangle<FLAT_ONLY, false>(T, S, draws, tex, stats);
         }
         cur = nxt;
     }
