@@ -38,7 +38,7 @@ def cpu_baseline(clip, col, W, H, sample):
     (oracle/_ref, built -O3 -DNDEBUG -ffp-contract=off) when it travelled to this box, else the C restatement."""
     from oracle import orc
     n = min(sample, clip.shape[0])
-    desc = f"first {n} triangles of the same 4096x4096 scene, rasterize() loop only"
+    desc = (f"all {n} triangles of the same frame" if n == clip.shape[0] else f"first {n} triangles of the same scene") + ", rasterize() loop only"
     if os.path.exists(orc.REF_HARNESS_FAST):
         from tinyrenderder_amd import scenes
         _, _, _, secs = orc.run_reference(W, H, 3, scenes.init_viewport(0, 0, W, H), [(orc.FLAT, None, clip[:n], None, col[:n])],
@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--triangles", type=int, default=10_000_000)
     ap.add_argument("--size", type=int, default=4096)
-    ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="triangles timed on the host CPU (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="triangles timed on the host CPU (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL strip-gather path even with one rank (rehearsal)")
     ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3"],
                     help="c4 (default, the metric's config): 10 M random flat triangles; c2/c3: PHONG head stand-in at 2048/4096")

@@ -223,6 +223,16 @@ int trgl_postprocess(trgl_ctx* ctx, const trgl_ssao_params* params, uint8_t* zbu
 size_t trgl_tga_max_size(int w, int h, int bpp);
 int trgl_tga_encode(const uint8_t* pixels, int w, int h, int bpp, int vflip, int rle, uint8_t* out, size_t* out_len);
 
+/* ---- OBJ reader (host only) -------------------------------------------------- */
+
+/* Stands in for the Assimp import of model.cpp:89-205 (fan triangulation, FlipUVs, float precision, one vertex per
+ * distinct v/vt/vn triple, the normal fallback of model.cpp:269-316).  On success *vertices holds *n_vertices records
+ * of 14 doubles (the reference's `Vertex`, model.h:14-20) and *indices 3 * *n_faces uint32, both owned by the library
+ * until trgl_obj_free.  Assimp's own vertex/face reordering is not reproducible: parity unpinned (tinyrenderder_amd/
+ * shim/trgl_obj.h).  Needs no GPU. */
+int trgl_obj_load(const char* path, double** vertices, uint64_t* n_vertices, uint32_t** indices, uint64_t* n_faces);
+void trgl_obj_free(double* vertices, uint32_t* indices);
+
 /* Self-test of the kernel's two exactness shortcuts (division by the per-triangle constant u.z through a
  * correctly rounded reciprocal + FMA corrections, and the division-free coverage signs) against the GPU's own
  * IEEE fp64 division, on `samples` random and adversarial operand pairs (all-ones significands, quotients next to

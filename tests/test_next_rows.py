@@ -114,3 +114,85 @@ def test_gpu_postprocess_4096():
     ao_crop = orc.ssao(np.ascontiguousarray(z[y0:y1]))
     assert np.array_equal(out["ao"][1000:1200], ao_crop[16:216])
     assert np.array_equal(out["final"], orc.composite(fb, out["ao"]))
+
+
+def _write_obj(path, level=2, with_normals=True):
+    """An OBJ of the icosphere with shared positions, quads mixed in, negative indices and v/vt/vn forms."""
+    tris = scenes.icosphere(level)                                   # [F,3,3]
+    pts = tris.reshape(-1, 3)
+    uniq, inv = np.unique(np.round(pts, 12), axis=0, return_inverse=True)
+    inv = inv.reshape(-1, 3)
+    uv = np.stack([uniq[:, 0] * 0.25 + 0.5, uniq[:, 1] * 0.25 + 0.5], 1)
+    with open(path, "w") as f:
+        f.write("# generated\n")
+        for p in uniq: f.write("v %.9g %.9g %.9g\n" % tuple(p))
+        for t in uv: f.write("vt %.9g %.9g\n" % tuple(t))
+        if with_normals:
+            for p in uniq: f.write("vn %.9g %.9g %.9g\n" % tuple(p))
+        n = len(uniq)
+        for k, (a, b, c) in enumerate(inv):
+            if with_normals:
+                if k % 3 == 0:
+                    f.write(f"f {a+1}/{a+1}/{a+1} {b+1}/{b+1}/{b+1} {c+1}/{c+1}/{c+1}\n")
+                elif k % 3 == 1:
+                    f.write(f"f {a-n}/{a-n}/{a-n} {b-n}/{b-n}/{b-n} {c-n}/{c-n}/{c-n}\n")      # relative indices
+                else:
+                    f.write(f"f {a+1}/{a+1}/{a+1} {b+1}/{b+1}/{b+1} {c+1}/{c+1}/{c+1} {c+1}/{c+1}/{c+1}\n")   # a (degenerate) quad: 2 fan triangles
+            else:
+                f.write(f"f {a+1}/{a+1} {b+1}/{b+1} {c+1}/{c+1}\n")
+    return uniq, uv, inv
+
+
+def test_obj_loader_layout_flipuv_fan_and_normals(tmp_path):
+    from tinyrenderder_amd import api
+    path = str(tmp_path / "ico.obj")
+    uniq, uv, inv = _write_obj(path, 2, with_normals=True)
+    verts, idx = api.load_obj(path)
+    f32 = lambda a: np.asarray(a, np.float64).astype(np.float32)
+    # one vertex per distinct triple, in order of first use
+    order = []
+    for a in inv.reshape(-1):
+        if a not in order: order.append(a)
+    assert verts.shape == (len(order), 14)
+    assert np.array_equal(verts[:, 0:3], f32(np.array([[float("%.9g" % c) for c in uniq[a]] for a in order])).astype(np.float64))
+    assert np.array_equal(verts[:, 7], (np.float32(1.0) - f32([float("%.9g" % uv[a, 1]) for a in order])).astype(np.float64))   # FlipUVs in float
+    assert np.all(verts[:, 8:] == 0)
+    nquads = len(range(2, len(inv), 3))
+    assert idx.shape[0] == len(inv) + nquads                         # each quad became two fan triangles
+    remap = {a: k for k, a in enumerate(order)}
+    assert np.array_equal(idx[0], [remap[a] for a in inv[0]])
+    # without vn: the reference's own fallback, model.cpp:269-316 (area-weighted smooth normals, normalised)
+    path2 = str(tmp_path / "ico_nonormals.obj")
+    _write_obj(path2, 2, with_normals=False)
+    v2, i2 = api.load_obj(path2)
+    ln = np.sqrt((v2[:, 3:6] ** 2).sum(1))
+    assert np.allclose(ln, 1.0, atol=1e-12)
+    assert (np.einsum("ij,ij->i", v2[:, 3:6], v2[:, 0:3]) > 0.9).all()      # on a sphere they point outwards
+    with pytest.raises(api.TrglError):
+        api.load_obj(str(tmp_path / "missing.obj"))
+
+
+@pytest.mark.gpu
+def test_obj_to_screen_through_device_vertex_stage(tmp_path):
+    """OBJ file -> trgl_obj_load -> trgl_draw_indexed (vertex stage + PHONG on the GPU) vs the oracle on the same arrays."""
+    from tinyrenderder_amd import api
+    from tinyrenderder_amd.api import Context, PHONG, make_uniforms
+    path = str(tmp_path / "ico.obj")
+    _write_obj(path, 4, with_normals=True)
+    verts, idx = api.load_obj(path)
+    W, H = 512, 384
+    hd = scenes.head_standin(1, W, H)                                # only for its camera and lights
+    d, n, s = scenes.procedural_textures(128)
+    u = make_uniforms(hd["model_view"], hd["key"], hd["fill"], hd["rim"], 1.0, 0, 1, 2)
+    with Context(W, H, 3) as ctx:
+        for k, t in enumerate((d, n, s)):
+            ctx.upload_texture(k, t)
+        ctx.draw_indexed(PHONG, u, hd["projection"], verts, idx)
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    clip, vary = orc.vertex_stage(hd["model_view"], hd["projection"], verts, idx)
+    o = orc.Oracle(W, H, 3)
+    for k, t in enumerate((d, n, s)):
+        o.upload_texture(k, t)
+    o.draw(orc.PHONG, clip, vary, uniforms=orc.make_uniforms(hd["model_view"], hd["key"], hd["fill"], hd["rim"], 1.0, 0, 1, 2))
+    assert np.array_equal(z.view(np.uint64), o.z.view(np.uint64)) and np.array_equal(fb, o.fb) and st == o.stats
+    assert st[1] > 10_000

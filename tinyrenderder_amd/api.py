@@ -28,7 +28,7 @@ SYMBOLS = [
     "trgl_format_stats", "trgl_framebuffer_device_ptr", "trgl_zbuffer_device_ptr", "trgl_stream", "trgl_set_stream",
     "trgl_set_profiling", "trgl_get_phase_ms", "trgl_reset_phase_ms", "trgl_get_last_flush_info",
     "trgl_selftest_division", "trgl_tga_max_size", "trgl_tga_encode", "trgl_draw_indexed", "trgl_ssao_defaults",
-    "trgl_postprocess",
+    "trgl_postprocess", "trgl_obj_load", "trgl_obj_free",
 ]
 
 
@@ -127,6 +127,9 @@ def load_library(path: str = LIB_PATH):
     L.trgl_ssao_defaults.argtypes = [C.POINTER(SsaoParams)]
     L.trgl_ssao_defaults.restype = None
     L.trgl_postprocess.argtypes = [vp, C.POINTER(SsaoParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.trgl_obj_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_double)), u64p, C.POINTER(C.POINTER(C.c_uint32)), u64p]
+    L.trgl_obj_free.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.trgl_obj_free.restype = None
     L.trgl_tga_max_size.argtypes = [C.c_int, C.c_int, C.c_int]
     L.trgl_tga_max_size.restype = C.c_size_t
     L.trgl_tga_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_size_t)]
@@ -162,6 +165,22 @@ def tga_encode(img, vflip: bool = True, rle: bool = True) -> bytes:
     if rc != 0:
         raise TrglError(f"trgl_tga_encode failed ({rc})")
     return out[:n.value].tobytes()
+
+
+def load_obj(path: str):
+    """Wavefront OBJ -> (vertices [nv,14] f64 in the reference's Vertex layout, indices [nf,3] u32).  Host only."""
+    L = load_library()
+    v, i = C.POINTER(C.c_double)(), C.POINTER(C.c_uint32)()
+    nv, nf = C.c_uint64(), C.c_uint64()
+    rc = L.trgl_obj_load(path.encode(), C.byref(v), C.byref(nv), C.byref(i), C.byref(nf))
+    if rc != 0:
+        raise TrglError(f"trgl_obj_load failed ({rc}): {L.trgl_last_error(None).decode()}")
+    try:
+        verts = np.ctypeslib.as_array(v, shape=(nv.value, 14)).copy() if nv.value else np.zeros((0, 14))
+        idx = np.ctypeslib.as_array(i, shape=(nf.value, 3)).copy() if nf.value else np.zeros((0, 3), np.uint32)
+    finally:
+        L.trgl_obj_free(v, i)
+    return verts, idx
 
 
 class Context:

@@ -247,6 +247,9 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, TileState& S,
             const int x = bx + (lane & 7), y = by + (lane >> 3);
             const bool act = (x <= x1) && (y <= y1);
             TRGL_DBG(1, 1);                                                    // blocks entering the coverage test
+#ifdef TRGL_DEBUG_COUNTERS
+            if (WELL_SCALED && __ballot(act && T.zbound < S.zt[lds_index(x, y)]) == 0) TRGL_DBG(5, 1);   // no lane of the block could pass
+#endif
             // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
             const double pxc = (double)x + 0.5, pyc = (double)y + 0.5;        // :149
             const double s0z = T.ax - pxc, s1z = T.ay - pyc;
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
     uint32_t frags = S.frags;
     const double zmin = S.zmin, zmax = S.zmax;
 #ifdef TRGL_DEBUG_COUNTERS
-    if (lane == 0) { for (int k = 0; k < 4; ++k) atomicAdd(&stats->dbg[k], S.dbg[k]); atomicAdd(&stats->dbg[4], (unsigned long long)(end - beg)); }
+    if (lane == 0) { for (int k = 0; k < 4; ++k) atomicAdd(&stats->dbg[k], S.dbg[k]); atomicAdd(&stats->dbg[5], S.dbg[5]); atomicAdd(&stats->dbg[4], (unsigned long long)(end - beg)); }
 #endif
 
     // ---- tile out: row-contiguous stores --------------------------------------------------------

@@ -18,6 +18,7 @@
 #include "launch.h"
 #include "trgl_device.h"
 #include "../shim/trgl_image.h"
+#include "../shim/trgl_obj.h"
 
 using namespace trgl;
 
@@ -578,6 +579,20 @@ int trgl_format_stats(const trgl_stats* s, char* buf, size_t buflen) {   // our_
 void* trgl_framebuffer_device_ptr(trgl_ctx* c) { return c ? c->fb : nullptr; }
 void* trgl_zbuffer_device_ptr(trgl_ctx* c) { return c ? c->zb : nullptr; }
 void* trgl_stream(trgl_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int trgl_obj_load(const char* path, double** vertices, uint64_t* n_vertices, uint32_t** indices, uint64_t* n_faces) {
+    if (!path || !vertices || !n_vertices || !indices || !n_faces) return TRGL_E_INVALID;
+    trgl_obj::Mesh m;
+    if (!trgl_obj::load(path, m)) { g_create_error = m.error; return TRGL_E_INVALID; }
+    *n_vertices = m.vertices.size() / 14; *n_faces = m.indices.size() / 3;
+    *vertices = (double*)std::malloc(m.vertices.size() * sizeof(double) + 8);
+    *indices = (uint32_t*)std::malloc(m.indices.size() * sizeof(uint32_t) + 8);
+    if (!*vertices || !*indices) { std::free(*vertices); std::free(*indices); return TRGL_E_NOMEM; }
+    std::memcpy(*vertices, m.vertices.data(), m.vertices.size() * sizeof(double));
+    std::memcpy(*indices, m.indices.data(), m.indices.size() * sizeof(uint32_t));
+    return TRGL_OK;
+}
+void trgl_obj_free(double* vertices, uint32_t* indices) { std::free(vertices); std::free(indices); }
 
 size_t trgl_tga_max_size(int w, int h, int bpp) {
     if (w <= 0 || h <= 0 || bpp <= 0) return 18;
