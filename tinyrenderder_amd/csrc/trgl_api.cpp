@@ -628,7 +628,9 @@ int trgl_selftest_division(trgl_ctx* c, uint64_t samples, uint64_t seed, uint64_
 
 int trgl_set_stream(trgl_ctx* c, void* hip_stream, int use_own) {
     CHKCTX(c);
-    int r = trgl_flush(c); if (r) return r;
+    int r = TRGL_OK;
+    if (!c->draws.empty()) r = trgl_flush(c);      // a pending clear alone needs no launch: it stays pending
+    if (r) return r;
     if ((r = resolve_events(c))) return r;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // a NULL hipStream_t is a real stream (the legacy default stream, which is what torch's current stream
