@@ -235,9 +235,17 @@ struct TileState {
 // our_gl.cpp:147-199 for one triangle on one tile: 8x8 pixel blocks, one pixel per lane.
 // WELL_SCALED (see k_setup) selects the division-free coverage test and the FMA division by u.z; everything
 // after the coverage test sits under `if (cov)`, so a block with no covered pixel costs two scalar instructions.
-template <bool FLAT_ONLY, bool WELL_SCALED>
-__device__ __forceinline__ void raster_triangle(const TriConst& T, TileState& S, const DrawDesc* __restrict__ draws,
+// KIND: the flush's shader kind when every draw has the same one (TRGL_SHADER_*), or KIND_ANY (per-triangle switch).
+// For GOURAUD / PHONG / EYE the triangle's varyings sit in lane j of the batch registers V (loaded with the records,
+// so the fragment branch never waits on memory) and are broadcast where a block actually shades.
+constexpr int KIND_ANY = 4;
+struct VaryQ { uint4 v[12]; uint32_t color; };      // 24 doubles of varyings (K <= 24) + the GOURAUD base colour
+
+template <int KIND, bool WELL_SCALED>
+__device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& V, uint32_t j, TileState& S,
+                                                const DrawDesc* __restrict__ draws,
                                                 const DevTexture* __restrict__ tex, DevStats* __restrict__ stats) {
+    constexpr bool FLAT_ONLY = KIND == TRGL_SHADER_FLAT;
     const int lane = S.lane;
     const double uz = T.uz, ruz = T.ruz;
     const int x0 = max((int)(T.bb0 & 0xffff), S.px0), x1 = min((int)(T.bb1 & 0xffff), S.xa1);
@@ -291,18 +299,32 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, TileState& S,
                         color = T.color;
                     } else {
                         const DrawDesc& d = draws[T.dl >> 24];
-                        if (d.kind == TRGL_SHADER_FLAT) {
+                        const int kind = KIND == KIND_ANY ? d.kind : KIND;
+                        if (kind == TRGL_SHADER_FLAT) {
                             color = T.color;
                         } else {
-                            const uint32_t local = T.dl & 0xffffffu;
                             double pc[3];
                             const double denom = b0 * T.iw0 + b1 * T.iw1 + b2 * T.iw2;            // :172-174
                             if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }      // :177-185
                             else { pc[0] = (b0 * T.iw0) / denom; pc[1] = (b1 * T.iw1) / denom; pc[2] = (b2 * T.iw2) / denom; }
-                            const double* vary = d.vary + (size_t)local * d.K;
-                            if (d.kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(d.colors ? d.colors[local] : 0xffffffffu, vary, pc);
-                            else if (d.kind == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
-                            else color = frag_eye(d.u, tex, vary, pc).bgra;
+                            if (KIND == KIND_ANY) {
+                                const uint32_t local = T.dl & 0xffffffu;
+                                const double* vary = d.vary + (size_t)local * d.K;
+                                if (kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(d.colors ? d.colors[local] : 0xffffffffu, vary, pc);
+                                else if (kind == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
+                                else color = frag_eye(d.u, tex, vary, pc).bgra;
+                            } else {
+                                double vary[24];
+                                constexpr int NV = KIND == TRGL_SHADER_GOURAUD ? 3 : 24;
+#pragma unroll
+                                for (int k = 0; k < NV; ++k) {
+                                    const uint4& q = V.v[k >> 1];
+                                    vary[k] = (k & 1) ? bcast_d(q.z, q.w, j) : bcast_d(q.x, q.y, j);
+                                }
+                                if (KIND == TRGL_SHADER_GOURAUD) color = frag_gouraud(bcast_u(V.color, j), vary, pc);
+                                else if (KIND == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
+                                else color = frag_eye(d.u, tex, vary, pc).bgra;
+                            }
                         }
                     }
                     S.zt[li] = z;                                             // :191
@@ -325,7 +347,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, TileState& S,
     }
 }
 
-template <bool FLAT_ONLY>
+template <int KIND>
 __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
                                                 const uint32_t* __restrict__ tile_start,
@@ -387,6 +409,8 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
         }
     }
 
+    constexpr bool FLAT_ONLY = KIND == TRGL_SHADER_FLAT;
+    constexpr bool HAS_V = KIND == TRGL_SHADER_GOURAUD || KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE;
     TileState S;
 #ifdef TRGL_DEBUG_COUNTERS
     for (int k = 0; k < 8; ++k) S.dbg[k] = 0;
@@ -410,6 +434,10 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
         for (int k = 0; k < 8; ++k) cur.q[k] = make_uint4(0, 0, 0, 0);
     }
     double* hz = s_hz[w];
+    VaryQ V;
+    V.color = 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) V.v[k] = make_uint4(0, 0, 0, 0);
     for (uint32_t bs = beg; bs < end; bs += 64) {
         const uint32_t nbatch = min(64u, end - bs);
         RecQ nxt = cur;
@@ -472,6 +500,22 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                 skip = behind;
             }
             todo = __ballot(!skip);
+            if (HAS_V && !skip) {        // this lane's triangle will be rasterized: fetch its varyings now
+                const uint32_t dl = cur.q[7].w;
+                const DrawDesc& d = draws[dl >> 24];
+                const uint32_t local = dl & 0xffffffu;
+                if (KIND == TRGL_SHADER_GOURAUD) {
+                    const double* vp = d.vary + (size_t)local * 3;
+                    const double a = vp[0], b = vp[1], c2 = vp[2];
+                    V.v[0] = make_uint4((uint32_t)__double2loint(a), (uint32_t)__double2hiint(a), (uint32_t)__double2loint(b), (uint32_t)__double2hiint(b));
+                    V.v[1] = make_uint4((uint32_t)__double2loint(c2), (uint32_t)__double2hiint(c2), 0u, 0u);
+                    V.color = d.colors ? d.colors[local] : 0xffffffffu;
+                } else {
+                    const uint4* vp = reinterpret_cast<const uint4*>(d.vary + (size_t)local * 24);   // 192-B records: 16-B aligned
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) V.v[k] = vp[k];
+                }
+            }
         }
         while (todo) {
             const uint32_t j = (uint32_t)__builtin_ctzll(todo);          // list order = ascending lane
@@ -491,8 +535,8 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
             T.tri = bcast_u(cur.tri, j);
             T.zbound = bcast_d((uint32_t)__double2loint(zbound_l), (uint32_t)__double2hiint(zbound_l), j);
             TRGL_DBG(0, 1);                                                    // list entries rasterized (not skipped)
-            if (T.ruz != 0.0) raster_triangle<FLAT_ONLY, true>(T, S, draws, tex, stats);    // wave-uniform
-            else raster_triangle<FLAT_ONLY, false>(T, S, draws, tex, stats);
+            if (T.ruz != 0.0) raster_triangle<KIND, true>(T, V, j, S, draws, tex, stats);    // wave-uniform
+            else raster_triangle<KIND, false>(T, V, j, S, draws, tex, stats);
         }
         cur = nxt;
     }
@@ -695,7 +739,7 @@ uint32_t raster_max_items(const FrameParams& fp, uint64_t pairs, uint32_t split_
     return (uint32_t)(tiles + extra);
 }
 
-void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const TriRec* recs, const uint32_t* vals,
+void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER_* if uniform over the flush, else -1 */, const TriRec* recs, const uint32_t* vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
                    const DevTexture* tex, DevStats* stats, uint32_t split_len, uint32_t max_items, uint32_t* items,
                    uint32_t* n_items, unsigned long long* item_stats) {
@@ -704,10 +748,15 @@ void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const T
     (void)hipMemsetAsync(n_items, 0, 4, s);
     hipLaunchKernelGGL(k_make_items, dim3((tiles + 255) / 256), dim3(256), 0, s, fp, tile_start, tile_end, split_len, items, n_items);
     dim3 grid((max_items + TRGL_WAVES_PER_BLOCK - 1) / TRGL_WAVES_PER_BLOCK);
-    if (flat_only)
-        hipLaunchKernelGGL(k_raster<true>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items, item_stats);
-    else
-        hipLaunchKernelGGL(k_raster<false>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items, item_stats);
+#define TRGL_LAUNCH_RASTER(K) hipLaunchKernelGGL(k_raster<K>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items, item_stats)
+    switch (kind) {
+    case TRGL_SHADER_FLAT:    TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT); break;
+    case TRGL_SHADER_GOURAUD: TRGL_LAUNCH_RASTER(TRGL_SHADER_GOURAUD); break;
+    case TRGL_SHADER_PHONG:   TRGL_LAUNCH_RASTER(TRGL_SHADER_PHONG); break;
+    case TRGL_SHADER_EYE:     TRGL_LAUNCH_RASTER(TRGL_SHADER_EYE); break;
+    default:                  TRGL_LAUNCH_RASTER(KIND_ANY); break;
+    }
+#undef TRGL_LAUNCH_RASTER
     hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(1024), 0, s, stats, n_items, item_stats);
 }
 

@@ -22,7 +22,7 @@ void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* v
 void launch_bounds(hipStream_t s, const uint32_t* keys, uint32_t P, uint32_t* tile_start, uint32_t* tile_end);
 
 uint32_t raster_max_items(const FrameParams& fp, uint64_t pairs, uint32_t split_len);
-void launch_raster(hipStream_t s, const FrameParams& fp, bool flat_only, const TriRec* recs, const uint32_t* vals,
+void launch_raster(hipStream_t s, const FrameParams& fp, int kind, const TriRec* recs, const uint32_t* vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
                    const DevTexture* tex, DevStats* stats, uint32_t split_len, uint32_t max_items, uint32_t* items,
                    uint32_t* n_items, unsigned long long* item_stats);

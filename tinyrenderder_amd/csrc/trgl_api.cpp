@@ -411,8 +411,8 @@ int trgl_flush(trgl_ctx* c) {
     fp.clear_color = c->clear_color; fp.clear_z = c->clear_z;
     std::memcpy(fp.vp, c->vp, sizeof(fp.vp));
 
-    bool flat_only = true;
-    for (auto& d : c->draws) if (d.kind != TRGL_SHADER_FLAT) flat_only = false;
+    int flush_kind = c->draws.empty() ? TRGL_SHADER_FLAT : c->draws[0].kind;     // one kind for the whole flush, or -1
+    for (auto& d : c->draws) if (d.kind != flush_kind) flush_kind = -1;
 
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
     uint32_t P = 0;
@@ -481,7 +481,7 @@ int trgl_flush(trgl_ctx* c) {
     const uint32_t max_items = raster_max_items(fp, P, split_len);
     if ((r = grow(c, c->items, c->cap_items, (size_t)max_items + 64))) return r;
     if ((r = grow(c, c->item_stats, c->cap_item_stats, ((size_t)max_items + 64) * 4))) return r;
-    launch_raster(s, fp, flat_only, recs_arg, vals_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev,
+    launch_raster(s, fp, flush_kind, recs_arg, vals_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev,
                   split_len, max_items, c->items, c->n_items, c->item_stats);
     if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[3], s)); c->events_pending = true; }
     HIPCHK(c, hipGetLastError());
