@@ -43,13 +43,19 @@ __device__ __forceinline__ const DevTexture* tex_slot(const DevTexture* tex, int
     if (!tex[slot].data || tex[slot].w <= 0) return nullptr;
     return &tex[slot];
 }
-__device__ __forceinline__ Color tex_fetch(const DevTexture* t, const double* uv) {
+// TGAImage::get at the clamped texel (model.cpp:420-425 etc.): ONE unaligned 4-byte load per texel (the device copy
+// of every texture is padded by 4 bytes), masked to bpp bytes = TGAColor(p, bpp) with the rest 0 (tgaimage.h:46-50).
+__device__ __forceinline__ uint32_t tex_fetch_raw(const DevTexture* t, const double* uv) {
     int x = iclamp(x86_cvttsd2si(uv[0] * t->w), 0, t->w - 1);
     int y = iclamp(x86_cvttsd2si(uv[1] * t->h), 0, t->h - 1);
     const uint8_t* p = t->data + ((size_t)x + (size_t)y * t->w) * t->bpp;
-    uint32_t v = 0;
-    for (int i = 0; i < t->bpp; ++i) v |= (uint32_t)p[i] << (8 * i);      // TGAColor(p,bpp): rest = 0
-    return Color{ v, t->bpp };
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint32_t tex_mask(const DevTexture* t) { return t->bpp >= 4 ? 0xffffffffu : ((1u << (8 * t->bpp)) - 1u); }
+__device__ __forceinline__ Color tex_fetch(const DevTexture* t, const double* uv) {
+    return Color{ tex_fetch_raw(t, uv) & tex_mask(t), t->bpp };
 }
 __device__ __forceinline__ void interp(const double* v0, const double* v1, const double* v2, const double* b, int n, double* out) {
     for (int i = 0; i < n; ++i) out[i] = (v0[i] * b[0] + v1[i] * b[1]) + v2[i] * b[2];       // main.cpp:94-104
@@ -67,10 +73,17 @@ __device__ Color frag_phong(const trgl_uniforms& u, const DevTexture* tx, const 
     interp(nrm, nrm + 3, nrm + 6, b, 3, geometry_normal);
     interp(uvv, uvv + 2, uvv + 4, b, 2, uv);
 
+    // the three maps are independent: issue all texel loads first, consume afterwards (the slots are per draw,
+    // so these branches are wave-uniform)
     const DevTexture* td = tex_slot(tx, u.tex_diffuse);
-    Color base = td ? tex_fetch(td, uv) : Color{ 0xffffffffu, 4 };                           // model.cpp:415-426
     const DevTexture* ts = tex_slot(tx, u.tex_specular);
-    float specf = ts ? (float)(int)(tex_fetch(ts, uv).bgra & 0xff) / 255.0f : 1.0f;           // model.cpp:447-459
+    const DevTexture* tn = tex_slot(tx, u.tex_normal);
+    uint32_t raw_d = 0, raw_s = 0, raw_n = 0;
+    if (td) raw_d = tex_fetch_raw(td, uv);
+    if (ts) raw_s = tex_fetch_raw(ts, uv);
+    if (tn) raw_n = tex_fetch_raw(tn, uv);
+    Color base = td ? Color{ raw_d & tex_mask(td), td->bpp } : Color{ 0xffffffffu, 4 };       // model.cpp:415-426
+    float specf = ts ? (float)(int)(raw_s & 0xff) / 255.0f : 1.0f;                            // model.cpp:447-459
     double specular_power = dmax(1.0, (double)specf);
 
     int bsum = (int)(base.bgra & 0xff) + (int)((base.bgra >> 8) & 0xff) + (int)((base.bgra >> 16) & 0xff);
@@ -78,13 +91,12 @@ __device__ Color frag_phong(const trgl_uniforms& u, const DevTexture* tx, const 
     bool is_eye_pixel = (brightness >= 0.85) && (specular_power <= 5.0);
 
     double nmv[3] = { 0, 0, 1 };                                                              // model.cpp:428-445
-    const DevTexture* tn = tex_slot(tx, u.tex_normal);
     if (tn) {
-        Color c = tex_fetch(tn, uv);
+        const uint32_t c = raw_n & tex_mask(tn);
         double n[3];
-        n[0] = (double)((c.bgra >> 16) & 0xff) / 255.0 * 2.0 - 1.0;
-        n[1] = (double)((c.bgra >> 8) & 0xff) / 255.0 * 2.0 - 1.0;
-        n[2] = (double)(c.bgra & 0xff) / 255.0 * 2.0 - 1.0;
+        n[0] = (double)((c >> 16) & 0xff) / 255.0 * 2.0 - 1.0;
+        n[1] = (double)((c >> 8) & 0xff) / 255.0 * 2.0 - 1.0;
+        n[2] = (double)(c & 0xff) / 255.0 * 2.0 - 1.0;
         normalized3(n, nmv);
     }
     double nme[3];                                                                            // main.cpp:116-119
@@ -136,7 +148,11 @@ __device__ Color frag_eye(const trgl_uniforms& u, const DevTexture* tx, const do
     interp(uvv, uvv + 2, uvv + 4, b, 2, uv);
 
     const DevTexture* td = tex_slot(tx, u.tex_diffuse);
-    Color base = td ? tex_fetch(td, uv) : Color{ 0xffffffffu, 4 };
+    const DevTexture* ts = tex_slot(tx, u.tex_specular);
+    uint32_t raw_d = 0, raw_s = 0;
+    if (td) raw_d = tex_fetch_raw(td, uv);
+    if (ts) raw_s = tex_fetch_raw(ts, uv);
+    Color base = td ? Color{ raw_d & tex_mask(td), td->bpp } : Color{ 0xffffffffu, 4 };
     double negp[3], V[3];
     for (int i = 0; i < 3; ++i) negp[i] = position_eye[i] * -1.0;
     normalized3(negp, V);
@@ -146,8 +162,7 @@ __device__ Color frag_eye(const trgl_uniforms& u, const DevTexture* tx, const do
     double rim_diffuse = dmax(0.0, dot3(N, u.rim_light_dir_eye)) * 0.6;
     double total_diffuse = key_diffuse + rim_diffuse;
 
-    const DevTexture* ts = tex_slot(tx, u.tex_specular);
-    float specf = ts ? (float)(int)(tex_fetch(ts, uv).bgra & 0xff) / 255.0f : 1.0f;
+    float specf = ts ? (float)(int)(raw_s & 0xff) / 255.0f : 1.0f;
     double specular_power = dmax(1.0, (double)specf) * 8.0;
     double k2 = 2.0 * dot3(N, Lk), rr[3], R[3];
     for (int i = 0; i < 3; ++i) rr[i] = N[i] * k2 - Lk[i];

@@ -221,7 +221,8 @@ int trgl_upload_texture(trgl_ctx* c, int slot, const uint8_t* texels, int w, int
     if (texels && w > 0 && h > 0) {
         if (!(bpp == 1 || bpp == 3 || bpp == 4)) return fail(c, TRGL_E_INVALID, "trgl_upload_texture: bpp must be 1, 3 or 4");
         uint8_t* d = nullptr; size_t bytes = (size_t)w * h * bpp;
-        HIPCHK(c, hipMalloc((void**)&d, bytes));
+        HIPCHK(c, hipMalloc((void**)&d, bytes + 8));         // +8: the samplers read each texel as one 4-byte load
+        HIPCHK(c, hipMemset(d + bytes, 0, 8));
         HIPCHK(c, hipMemcpy(d, texels, bytes, hipMemcpyHostToDevice));
         c->tex_host[slot] = DevTexture{ d, w, h, bpp, 0 };
     }
