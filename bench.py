@@ -173,7 +173,7 @@ def main():
             "tri_tile_pairs": info["pairs"],
             "phase_ms": {"setup": phase_ms[PHASE_SETUP] / max(nfl, 1), "bin": phase_ms[PHASE_BIN] / max(nfl, 1),
                          "raster": raster_ms, "flush_total": phase_ms[PHASE_TOTAL] / max(nfl, 1)},
-            "roofline": {"bound": "hbm", "kernel": "k_raster<flat>" if kind == FLAT else "k_raster<any shader>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_raster<flat>" if kind == FLAT else "k_raster<phong>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": raster_ms},
         }

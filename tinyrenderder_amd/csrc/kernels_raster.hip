@@ -254,7 +254,7 @@ struct TileState {
 // For GOURAUD / PHONG / EYE the triangle's varyings sit in lane j of the batch registers V (loaded with the records,
 // so the fragment branch never waits on memory) and are broadcast where a block actually shades.
 constexpr int KIND_ANY = 4;
-struct VaryQ { uint4 v[12]; uint32_t color; };      // 24 doubles of varyings (K <= 24) + the GOURAUD base colour
+struct VaryQ { uint4 v[2]; uint32_t color; };       // GOURAUD: three intensities + the base colour of lane j's triangle
 
 template <int KIND, bool WELL_SCALED>
 __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& V, uint32_t j, TileState& S,
@@ -322,23 +322,17 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                             const double denom = b0 * T.iw0 + b1 * T.iw1 + b2 * T.iw2;            // :172-174
                             if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }      // :177-185
                             else { pc[0] = (b0 * T.iw0) / denom; pc[1] = (b1 * T.iw1) / denom; pc[2] = (b2 * T.iw2) / denom; }
-                            if (KIND == KIND_ANY) {
+                            if (KIND != TRGL_SHADER_GOURAUD) {
                                 const uint32_t local = T.dl & 0xffffffu;
-                                const double* vary = d.vary + (size_t)local * d.K;
+                                const double* vary = d.vary + (size_t)local * (KIND == KIND_ANY ? d.K : 24);
                                 if (kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(d.colors ? d.colors[local] : 0xffffffffu, vary, pc);
                                 else if (kind == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
                                 else color = frag_eye(d.u, tex, vary, pc).bgra;
                             } else {
-                                double vary[24];
-                                constexpr int NV = KIND == TRGL_SHADER_GOURAUD ? 3 : 24;
-#pragma unroll
-                                for (int k = 0; k < NV; ++k) {
-                                    const uint4& q = V.v[k >> 1];
-                                    vary[k] = (k & 1) ? bcast_d(q.z, q.w, j) : bcast_d(q.x, q.y, j);
-                                }
-                                if (KIND == TRGL_SHADER_GOURAUD) color = frag_gouraud(bcast_u(V.color, j), vary, pc);
-                                else if (KIND == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
-                                else color = frag_eye(d.u, tex, vary, pc).bgra;
+                                double vary[3];
+                                vary[0] = bcast_d(V.v[0].x, V.v[0].y, j); vary[1] = bcast_d(V.v[0].z, V.v[0].w, j);
+                                vary[2] = bcast_d(V.v[1].x, V.v[1].y, j);
+                                color = frag_gouraud(bcast_u(V.color, j), vary, pc);
                             }
                         }
                     }
@@ -363,7 +357,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
                                                 const uint32_t* __restrict__ tile_start,
                                                 const uint32_t* __restrict__ tile_end,
@@ -425,7 +419,12 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
     }
 
     constexpr bool FLAT_ONLY = KIND == TRGL_SHADER_FLAT;
-    constexpr bool HAS_V = KIND == TRGL_SHADER_GOURAUD || KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE;
+    // GOURAUD's 3 intensities + base colour ride along with the records (lane j of V); PHONG / EYE have 24 doubles of
+    // varyings: holding them per lane costs 48 VGPRs and a third wave per SIMD, which is worth more than the latency
+    // of fetching them where a block shades (measured: 232 -> <=168 VGPRs).  For the same reason only the cheap kinds
+    // keep the next batch of records in flight.
+    constexpr bool HAS_V = KIND == TRGL_SHADER_GOURAUD;
+    constexpr bool PREFETCH = KIND == TRGL_SHADER_FLAT || KIND == TRGL_SHADER_GOURAUD;
     TileState S;
 #ifdef TRGL_DEBUG_COUNTERS
     for (int k = 0; k < 8; ++k) S.dbg[k] = 0;
@@ -450,13 +449,11 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
     }
     double* hz = s_hz[w];
     VaryQ V;
-    V.color = 0;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) V.v[k] = make_uint4(0, 0, 0, 0);
+    V.color = 0; V.v[0] = make_uint4(0, 0, 0, 0); V.v[1] = make_uint4(0, 0, 0, 0);
     for (uint32_t bs = beg; bs < end; bs += 64) {
         const uint32_t nbatch = min(64u, end - bs);
         RecQ nxt = cur;
-        if (bs + 64 < end) {
+        if (PREFETCH && bs + 64 < end) {
             uint32_t p = bs + 64 + lane;
             nxt = load_rec(recs, vals[p < end ? p : end - 1], true);
         }
@@ -519,17 +516,11 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                 const uint32_t dl = cur.q[7].w;
                 const DrawDesc& d = draws[dl >> 24];
                 const uint32_t local = dl & 0xffffffu;
-                if (KIND == TRGL_SHADER_GOURAUD) {
-                    const double* vp = d.vary + (size_t)local * 3;
-                    const double a = vp[0], b = vp[1], c2 = vp[2];
-                    V.v[0] = make_uint4((uint32_t)__double2loint(a), (uint32_t)__double2hiint(a), (uint32_t)__double2loint(b), (uint32_t)__double2hiint(b));
-                    V.v[1] = make_uint4((uint32_t)__double2loint(c2), (uint32_t)__double2hiint(c2), 0u, 0u);
-                    V.color = d.colors ? d.colors[local] : 0xffffffffu;
-                } else {
-                    const uint4* vp = reinterpret_cast<const uint4*>(d.vary + (size_t)local * 24);   // 192-B records: 16-B aligned
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) V.v[k] = vp[k];
-                }
+                const double* vp = d.vary + (size_t)local * 3;
+                const double a = vp[0], b = vp[1], c2 = vp[2];
+                V.v[0] = make_uint4((uint32_t)__double2loint(a), (uint32_t)__double2hiint(a), (uint32_t)__double2loint(b), (uint32_t)__double2hiint(b));
+                V.v[1] = make_uint4((uint32_t)__double2loint(c2), (uint32_t)__double2hiint(c2), 0u, 0u);
+                V.color = d.colors ? d.colors[local] : 0xffffffffu;
             }
         }
         while (todo) {
@@ -553,7 +544,11 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
             if (T.ruz != 0.0) raster_triangle<KIND, true>(T, V, j, S, draws, tex, stats);    // wave-uniform
             else raster_triangle<KIND, false>(T, V, j, S, draws, tex, stats);
         }
-        cur = nxt;
+        if (PREFETCH) cur = nxt;
+        else if (bs + 64 < end) {
+            uint32_t p = bs + 64 + lane;
+            cur = load_rec(recs, vals[p < end ? p : end - 1], true);
+        }
     }
 
     uint32_t frags = S.frags;
