@@ -69,7 +69,7 @@ def main():
 
     import torch
     from tinyrenderder_amd import scenes, shard
-    from tinyrenderder_amd.api import Context, FLAT, PHASE_RASTER, PHASE_SETUP, PHASE_BIN, PHASE_TOTAL
+    from tinyrenderder_amd.api import Context, FLAT, PHASE_RASTER, PHASE_SETUP, PHASE_BIN, PHASE_TOTAL, PHASE_RASTER_KERNEL
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -145,6 +145,19 @@ def main():
         elapsed = float(t.item())
     phase_ms, nfl = ctx.phase_ms()
     info = ctx.last_flush_info()
+    # frame write-out alone (outside the timed region): clear + flush with no triangles = k_raster storing W*H*(8+bpp)
+    # bytes once; BASELINE north_star's ">= 50 % of HBM roofline on framebuffer + z writes" is this figure
+    writeout = None
+    if world == 1:
+        ctx.reset_phase_ms()
+        for _ in range(20):
+            ctx.clear()
+            ctx.flush()
+        wo_ms, wo_n = ctx.phase_ms()
+        wo_us = wo_ms[PHASE_RASTER_KERNEL] / max(wo_n, 1) * 1e3
+        writeout = {"bytes": W * H * 11, "kernel": "k_raster on a cleared frame without triangles", "avg_launch_us": wo_us,
+                    "achieved": W * H * 11 / (wo_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": W * H * 11 / (wo_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
     ctx.set_profiling(False)
 
     if rank == 0:
@@ -153,7 +166,7 @@ def main():
         # dominant kernel = the tile raster; algorithmic bytes per launch: every pixel's colour and z
         # leave the chip once (W*H*11 B) and every triangle's clip-space vertices are consumed once (N*96 B).
         algo_bytes = (W * H * 11 + N * (96 + 8 * K)) / world
-        raster_ms = phase_ms[PHASE_RASTER] / max(nfl, 1)
+        raster_ms = phase_ms[PHASE_RASTER_KERNEL] / max(nfl, 1)       # the k_raster launch alone, HIP events on its stream
         achieved = algo_bytes / (raster_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -172,11 +185,14 @@ def main():
             "mpixels_per_s": W * H * args.steps / elapsed / 1e6,
             "tri_tile_pairs": info["pairs"],
             "phase_ms": {"setup": phase_ms[PHASE_SETUP] / max(nfl, 1), "bin": phase_ms[PHASE_BIN] / max(nfl, 1),
-                         "raster": raster_ms, "flush_total": phase_ms[PHASE_TOTAL] / max(nfl, 1)},
+                         "raster": phase_ms[PHASE_RASTER] / max(nfl, 1), "raster_kernel": raster_ms,
+                         "flush_total": phase_ms[PHASE_TOTAL] / max(nfl, 1)},
             "roofline": {"bound": "hbm", "kernel": "k_raster<flat>" if kind == FLAT else "k_raster<phong>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": raster_ms},
         }
+        if writeout:
+            out["writeout"] = writeout
         if world == 1 and args.cpu_sample > 0 and args.workload == "c4":
             out["cpu_baseline"] = cpu_baseline(clip, col, W, H, args.cpu_sample)
         print(json.dumps(out))

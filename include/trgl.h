@@ -98,7 +98,8 @@ typedef struct trgl_stats {
 #define TRGL_PHASE_BIN     1   /* scan + pair expansion + stable tile sort */
 #define TRGL_PHASE_RASTER  2   /* tile raster (coverage, z-test, fragment) + tile flush */
 #define TRGL_PHASE_TOTAL   3   /* first kernel to last kernel of a flush */
-#define TRGL_NUM_PHASES    4
+#define TRGL_PHASE_RASTER_KERNEL 4   /* the k_raster launch alone (RASTER also holds the work-item and counter-fold kernels) */
+#define TRGL_NUM_PHASES    5
 
 typedef struct trgl_ctx trgl_ctx;
 

@@ -12,5 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $A
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/bench_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/bench_pmc_write.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/bench_pmc_sq.log 2>&1
+# 3) the write-out-only frame (clear + flush without triangles) at 4096x4096: k_raster's duration = W*H*11 B leaving the chip
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_writeout -- python3 profiles/writeout_probe.py 4096 > $OUT/writeout.log 2>&1
 python3 profiles/summarize_rocprof.py $OUT > $OUT/summary.txt
 cat $OUT/summary.txt

@@ -1,5 +1,6 @@
 """Condense a profiles/run_rocprof.sh output directory into a small text summary (committed per round)."""
 import csv
+import re
 import glob
 import os
 import sys
@@ -9,8 +10,11 @@ out = sys.argv[1]
 
 
 def short(name):
-    for k in ("k_raster<true>", "k_raster<false>", "k_setup", "k_scan_reduce", "k_scan_spine", "k_scan_apply", "k_expand",
-              "k_radix_hist", "k_radix_scatter", "k_bounds", "k_fold_stats", "k_selftest_division"):
+    m = re.search(r"k_raster<(\d)>", name)
+    if m:
+        return "k_raster<" + ["flat", "gouraud", "phong", "eye", "any"][int(m.group(1))] + ">"
+    for k in ("k_setup", "k_scan_reduce", "k_scan_spine", "k_scan_apply", "k_expand", "k_radix_hist", "k_radix_scatter",
+              "k_bounds", "k_make_items", "k_fold_stats", "k_selftest_division"):
         if k in name:
             return k
     return name.split("(")[0][:60]
@@ -23,6 +27,17 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
     for r in rows:
         print(f"{short(r['Name']):28s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:10.3f} {float(r['AverageNs'])/1e3:10.1f} "
               f"{float(r['MinNs'])/1e3:10.1f} {float(r['MaxNs'])/1e3:10.1f} {float(r['Percentage']):6.2f}")
+
+for f in glob.glob(os.path.join(out, "trace_writeout", "**", "*kernel_stats.csv"), recursive=True):
+    print("\n== write-out-only frames at 4096x4096 (profiles/writeout_probe.py 4096: RGB then RGBA framebuffer, 25 frames each) ==")
+    for r in csv.DictReader(open(f)):
+        if "k_raster" in r["Name"]:
+            avg = float(r["AverageNs"])
+            print(f"{short(r['Name']):28s} calls {r['Calls']}  avg {avg/1e3:.1f} us  min {float(r['MinNs'])/1e3:.1f} us  -> "
+                  f"{4096*4096*11.5/avg:.0f} GB/s average over RGB (11 B/px) and RGBA (12 B/px) frames = {4096*4096*11.5/avg/8000*100:.1f} % of 8 TB/s")
+    log = os.path.join(out, "writeout.log")
+    if os.path.exists(log):
+        print(open(log).read().strip())
 
 for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
     files = glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True)

@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(HERE, "libtrgl.so")
 FLAT, GOURAUD, PHONG, EYE = 0, 1, 2, 3
 VARY = {FLAT: 0, GOURAUD: 3, PHONG: 24, EYE: 24}
 MEM_HOST, MEM_DEVICE = 0, 1
-PHASE_SETUP, PHASE_BIN, PHASE_RASTER, PHASE_TOTAL = 0, 1, 2, 3
+PHASE_SETUP, PHASE_BIN, PHASE_RASTER, PHASE_TOTAL, PHASE_RASTER_KERNEL = 0, 1, 2, 3, 4
+NUM_PHASES = 5        # TRGL_NUM_PHASES
 MAX_TEXTURES = 16
 
 # every symbol include/trgl.h declares (tests check the library exports all of them)
@@ -351,7 +352,7 @@ class Context:
         self._chk(self.L.trgl_set_profiling(self.h, 1 if on else 0))
 
     def phase_ms(self):
-        ms = (C.c_double * 4)()
+        ms = (C.c_double * NUM_PHASES)()
         n = C.c_uint64()
         self._chk(self.L.trgl_get_phase_ms(self.h, ms, C.byref(n)))
         return list(ms), n.value

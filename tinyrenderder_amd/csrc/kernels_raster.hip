@@ -231,6 +231,7 @@ struct TriConst {
     double ax, ay, s0x, s0y, s1x, s1y, uz, ruz, z0, z1, z2, iw0, iw1, iw2;
     double zbound;      // lower bound of the depth of any covered pixel (-inf if the triangle is not well scaled)
     uint32_t bb0, bb1, color, dl, tri;
+    uint32_t blocks;    // bit k set: the k-th 8x8 block of the scan (row-major from the clamped bbox corner) may hold covered pixels
 };
 // Per-wave tile state.
 #ifdef TRGL_DEBUG_COUNTERS
@@ -265,10 +266,20 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
     const double uz = T.uz, ruz = T.ruz;
     const int x0 = max((int)(T.bb0 & 0xffff), S.px0), x1 = min((int)(T.bb1 & 0xffff), S.xa1);
     const int y0 = max((int)(T.bb0 >> 16), S.ya0), y1 = min((int)(T.bb1 >> 16), S.ya1);
+    uint32_t blocks = T.blocks;
     for (int by = y0; by <= y1; by += 8) {
-        for (int bx = x0; bx <= x1; bx += 8) {
+        for (int bx = x0; bx <= x1; bx += 8, blocks >>= 1) {
             const int x = bx + (lane & 7), y = by + (lane >> 3);
             const bool act = (x <= x1) && (y <= y1);
+#ifdef TRGL_DEBUG_COUNTERS
+            if (!(blocks & 1u)) {                                              // a block the mask calls empty must be empty
+                TRGL_DBG(6, 1);
+                const double pxd = (double)x + 0.5, pyd = (double)y + 0.5, a0 = T.ax - pxd, a1 = T.ay - pyd;
+                const double vx = T.s0y * a1 - a0 * T.s1y, vy = a0 * T.s1x - T.s0x * a1;
+                if (__ballot(act && !(vx + vy < uz) && !(vy > 0.0) && !(vx > 0.0))) TRGL_DBG(7, 1);
+            }
+#endif
+            if (!(blocks & 1u)) continue;
             TRGL_DBG(1, 1);                                                    // blocks entering the coverage test
 #ifdef TRGL_DEBUG_COUNTERS
             if (WELL_SCALED && __ballot(act && T.zbound < S.zt[lds_index(x, y)]) == 0) TRGL_DBG(5, 1);   // no lane of the block could pass
@@ -356,6 +367,59 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
     }
 }
 
+// Tile out: row-contiguous stores of the wave's rows [ya0, ya1] x columns [px0, xa1].  CLEARED: the item has no
+// triangles and starts from the clear values, so they are stored directly (no LDS round trip; this is the whole
+// kernel on a clear-only frame, the "framebuffer + z write-out" figure of BASELINE.json).
+template <bool CLEARED>
+__device__ __forceinline__ void tile_out(const FrameParams& fp, const double* zt, const uint32_t* ct, int lane,
+                                         int px0, int py0, int xa1, int ya0, int ya1) {
+    const bool full_x = (px0 + TRGL_TILE - 1) <= xa1;
+    // z: 16 B per lane, 4 rows per store instruction
+    if (full_x && (fp.W & 1) == 0) {
+        for (int r4 = 0; r4 < TRGL_TILE; r4 += 4) {
+            int x = px0 + ((lane & 15) << 1), y = py0 + r4 + (lane >> 4);
+            if (y >= ya0 && y <= ya1) {
+                double2 v = CLEARED ? make_double2(fp.clear_z, fp.clear_z) : *reinterpret_cast<const double2*>(&zt[lds_index(x, y)]);
+                { typedef double nt_d2 __attribute__((ext_vector_type(2))); nt_d2 nv = {v.x, v.y}; __builtin_nontemporal_store(nv, reinterpret_cast<nt_d2*>(&fp.zb[(size_t)x + (size_t)y * fp.W])); }
+            }
+        }
+    } else {
+        for (int r2 = 0; r2 < TRGL_TILE; r2 += 2) {
+            int x = px0 + (lane & 31), y = py0 + r2 + (lane >> 5);
+            if (x <= xa1 && y >= ya0 && y <= ya1) fp.zb[(size_t)x + (size_t)y * fp.W] = CLEARED ? fp.clear_z : zt[lds_index(x, y)];
+        }
+    }
+    // colour: 4 pixels per lane (12 B for RGB, 16 B for RGBA), 8 rows per store instruction
+    if (full_x && (fp.W & 3) == 0 && (fp.bpp == 3 || fp.bpp == 4)) {
+        for (int r8 = 0; r8 < TRGL_TILE; r8 += 8) {
+            int x = px0 + ((lane & 7) << 2), y = py0 + r8 + (lane >> 3);
+            if (y >= ya0 && y <= ya1) {
+                uint4 c = CLEARED ? make_uint4(fp.clear_color, fp.clear_color, fp.clear_color, fp.clear_color) : *reinterpret_cast<const uint4*>(&ct[lds_index(x, y)]);
+                size_t idx = (size_t)x + (size_t)y * fp.W;
+                if (fp.bpp == 4) {
+                    { typedef uint32_t nt_u4 __attribute__((ext_vector_type(4))); nt_u4 nv = {c.x, c.y, c.z, c.w}; __builtin_nontemporal_store(nv, reinterpret_cast<nt_u4*>(fp.fb + idx * 4)); }
+                } else {
+                    uint32_t d0 = (c.x & 0xffffffu) | (c.y << 24);
+                    uint32_t d1 = ((c.y >> 8) & 0xffffu) | (c.z << 16);
+                    uint32_t d2 = ((c.z >> 16) & 0xffu) | (c.w << 8);
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(fp.fb + idx * 3);
+                    dst[0] = d0; dst[1] = d1; dst[2] = d2;
+                }
+            }
+        }
+    } else {
+        for (int r2 = 0; r2 < TRGL_TILE; r2 += 2) {
+            int x = px0 + (lane & 31), y = py0 + r2 + (lane >> 5);
+            if (x <= xa1 && y >= ya0 && y <= ya1) {
+                uint32_t c = CLEARED ? fp.clear_color : ct[lds_index(x, y)];
+                uint8_t* dst = fp.fb + ((size_t)x + (size_t)y * fp.W) * fp.bpp;
+                for (int i = 0; i < fp.bpp; ++i) dst[i] = (uint8_t)(c >> (8 * i));
+            }
+        }
+    }
+
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
@@ -399,6 +463,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
     double* zt = s_z[w];
     uint32_t* ct = s_c[w];
+    if (fp.init_from_clear && beg == end) {              // cleared and empty: store the clear values, nothing else
+        tile_out<true>(fp, zt, ct, lane, px0, py0, xa1, ya0, ya1);
+        if (lane == 0) {
+            ulonglong2* dst = reinterpret_cast<ulonglong2*>(item_stats + (size_t)item_idx * 4);
+            dst[0] = make_ulonglong2(0ull, ~0ull); dst[1] = make_ulonglong2(0ull, 0ull);
+        }
+        return;
+    }
 
     // ---- tile in: clear values, or the current framebuffer / z-buffer contents --------------------
     if (fp.init_from_clear) {
@@ -485,6 +557,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         unsigned long long todo;
         double zbound_l = -__builtin_inf();       // this lane's triangle: lower bound of its covered depths
+        uint32_t blocks_l = 0xffffu;              // ... and which blocks of its scan can hold covered pixels
         {
             const int bx0 = (int)(cur.q[7].x & 0xffff), by0 = (int)(cur.q[7].x >> 16);
             const int bx1 = (int)(cur.q[7].y & 0xffff), by1 = (int)(cur.q[7].y >> 16);
@@ -510,6 +583,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                             if (!(zbound >= hz[64 + cyy * 4 + cxx])) { behind = false; break; }
                 }
                 skip = behind;
+                if (!behind) {
+                    // Which 8x8 blocks of the scan can hold covered pixels at all?  A pixel is covered iff the rounded
+                    // u.x <= 0, u.y <= 0 and u.x+u.y >= u.z (raster_triangle); each is an affine function of the pixel
+                    // centre, so over a block its extreme sits at a corner chosen by the gradient's signs.  The corner
+                    // values are stepped block to block; every rounding involved (here and in the per-pixel
+                    // evaluation) is below 2^-48 * (|a|+|b|) * R, R bounding |A - pixel| on the tile, and the test
+                    // keeps a margin of 2^-40 of that: a block is dropped only when one edge excludes all of it.
+                    const double ax = __hiloint2double((int)cur.q[0].y, (int)cur.q[0].x), ay = __hiloint2double((int)cur.q[0].w, (int)cur.q[0].z);
+                    const double s0x = __hiloint2double((int)cur.q[1].y, (int)cur.q[1].x), s0y = __hiloint2double((int)cur.q[1].w, (int)cur.q[1].z);
+                    const double s1x = __hiloint2double((int)cur.q[2].y, (int)cur.q[2].x), s1y = __hiloint2double((int)cur.q[2].w, (int)cur.q[2].z);
+                    const double uz_l = __hiloint2double((int)cur.q[3].y, (int)cur.q[3].x);
+                    const double X0 = (double)x0 + 0.5, Y0 = (double)y0 + 0.5;
+                    const double gx = s1y - s1x, gy = s0x - s0y;
+                    const double dxa = ax - (X0 + (s1y >= 0.0 ? 0.0 : 7.0)), dya = ay - (Y0 + (s0y <= 0.0 ? 0.0 : 7.0));   // min of u.x
+                    const double dxb = ax - (X0 + (s1x <= 0.0 ? 0.0 : 7.0)), dyb = ay - (Y0 + (s0x >= 0.0 ? 0.0 : 7.0));   // min of u.y
+                    const double dxc = ax - (X0 + (gx >= 0.0 ? 7.0 : 0.0)), dyc = ay - (Y0 + (gy >= 0.0 ? 7.0 : 0.0));     // max of u.x+u.y
+                    double fa_row = s0y * dya - dxa * s1y;
+                    double fb_row = dxb * s1x - s0x * dyb;
+                    double fc_row = (s0y * dyc - dxc * s1y) + (dxc * s1x - s0x * dyc);
+                    const double R = fabs(ax - X0) + fabs(ay - Y0) + 64.0;
+                    const double ma = 0x1p-40 * ((fabs(s0y) + fabs(s1y)) * R), mb = 0x1p-40 * ((fabs(s0x) + fabs(s1x)) * R);
+                    const double lim_c = uz_l - (ma + mb);
+                    const double sax = 8.0 * s1y, say = -8.0 * s0y, sbx = -8.0 * s1x, sby = 8.0 * s0x, scx = 8.0 * gx, scy = 8.0 * gy;
+                    const int nbx = ((x1 - x0) >> 3) + 1, nby = ((y1 - y0) >> 3) + 1;
+                    uint32_t m = 0, bit = 1;
+                    for (int iy = 0; iy < nby; ++iy) {
+                        double fa = fa_row, fb = fb_row, fc = fc_row;
+                        for (int ix = 0; ix < nbx; ++ix) {
+                            if (!(fa > ma || fb > mb || fc < lim_c)) m |= bit;
+                            bit <<= 1;
+                            fa += sax; fb += sbx; fc += scx;
+                        }
+                        fa_row += say; fb_row += sby; fc_row += scy;
+                    }
+                    blocks_l = m;
+                    skip = m == 0;
+                }
             }
             todo = __ballot(!skip);
             if (HAS_V && !skip) {        // this lane's triangle will be rasterized: fetch its varyings now
@@ -538,7 +648,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 T.iw2 = bcast_d(cur.q[6].z, cur.q[6].w, j); T.dl = bcast_u(cur.q[7].w, j);
             }
             T.bb0 = bcast_u(cur.q[7].x, j); T.bb1 = bcast_u(cur.q[7].y, j); T.color = bcast_u(cur.q[7].z, j);
-            T.tri = bcast_u(cur.tri, j);
+            T.tri = bcast_u(cur.tri, j); T.blocks = bcast_u(blocks_l, j);
             T.zbound = bcast_d((uint32_t)__double2loint(zbound_l), (uint32_t)__double2hiint(zbound_l), j);
             TRGL_DBG(0, 1);                                                    // list entries rasterized (not skipped)
             if (T.ruz != 0.0) raster_triangle<KIND, true>(T, V, j, S, draws, tex, stats);    // wave-uniform
@@ -554,54 +664,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     uint32_t frags = S.frags;
     const double zmin = S.zmin, zmax = S.zmax;
 #ifdef TRGL_DEBUG_COUNTERS
-    if (lane == 0) { for (int k = 0; k < 4; ++k) atomicAdd(&stats->dbg[k], S.dbg[k]); atomicAdd(&stats->dbg[5], S.dbg[5]); atomicAdd(&stats->dbg[4], (unsigned long long)(end - beg)); }
+    if (lane == 0) { for (int k = 0; k < 4; ++k) atomicAdd(&stats->dbg[k], S.dbg[k]); atomicAdd(&stats->dbg[5], S.dbg[5]); atomicAdd(&stats->dbg[6], S.dbg[6]); atomicAdd(&stats->dbg[7], S.dbg[7]); atomicAdd(&stats->dbg[4], (unsigned long long)(end - beg)); }
 #endif
 
-    // ---- tile out: row-contiguous stores --------------------------------------------------------
-    const bool full_x = (px0 + TRGL_TILE - 1) <= xa1;
-    // z: 16 B per lane, 4 rows per store instruction
-    if (full_x && (fp.W & 1) == 0) {
-        for (int r4 = 0; r4 < TRGL_TILE; r4 += 4) {
-            int x = px0 + ((lane & 15) << 1), y = py0 + r4 + (lane >> 4);
-            if (y >= ya0 && y <= ya1) {
-                double2 v = *reinterpret_cast<const double2*>(&zt[lds_index(x, y)]);
-                *reinterpret_cast<double2*>(&fp.zb[(size_t)x + (size_t)y * fp.W]) = v;
-            }
-        }
-    } else {
-        for (int r2 = 0; r2 < TRGL_TILE; r2 += 2) {
-            int x = px0 + (lane & 31), y = py0 + r2 + (lane >> 5);
-            if (x <= xa1 && y >= ya0 && y <= ya1) fp.zb[(size_t)x + (size_t)y * fp.W] = zt[lds_index(x, y)];
-        }
-    }
-    // colour: 4 pixels per lane (12 B for RGB, 16 B for RGBA), 8 rows per store instruction
-    if (full_x && (fp.W & 3) == 0 && (fp.bpp == 3 || fp.bpp == 4)) {
-        for (int r8 = 0; r8 < TRGL_TILE; r8 += 8) {
-            int x = px0 + ((lane & 7) << 2), y = py0 + r8 + (lane >> 3);
-            if (y >= ya0 && y <= ya1) {
-                uint4 c = *reinterpret_cast<const uint4*>(&ct[lds_index(x, y)]);
-                size_t idx = (size_t)x + (size_t)y * fp.W;
-                if (fp.bpp == 4) {
-                    *reinterpret_cast<uint4*>(fp.fb + idx * 4) = c;
-                } else {
-                    uint32_t d0 = (c.x & 0xffffffu) | (c.y << 24);
-                    uint32_t d1 = ((c.y >> 8) & 0xffffu) | (c.z << 16);
-                    uint32_t d2 = ((c.z >> 16) & 0xffu) | (c.w << 8);
-                    uint32_t* dst = reinterpret_cast<uint32_t*>(fp.fb + idx * 3);
-                    dst[0] = d0; dst[1] = d1; dst[2] = d2;
-                }
-            }
-        }
-    } else {
-        for (int r2 = 0; r2 < TRGL_TILE; r2 += 2) {
-            int x = px0 + (lane & 31), y = py0 + r2 + (lane >> 5);
-            if (x <= xa1 && y >= ya0 && y <= ya1) {
-                uint32_t c = ct[lds_index(x, y)];
-                uint8_t* dst = fp.fb + ((size_t)x + (size_t)y * fp.W) * fp.bpp;
-                for (int i = 0; i < fp.bpp; ++i) dst[i] = (uint8_t)(c >> (8 * i));
-            }
-        }
-    }
+    // ---- tile out ----------------------------------------------------------------------------
+    tile_out<false>(fp, zt, ct, lane, px0, py0, xa1, ya0, ya1);
 
     // ---- stats: our_gl.cpp:194-198, reduced per wave, one set of atomics per tile -----------------
     unsigned long long kmin = zkey(zmin), kmax = zkey(zmax);
@@ -752,12 +819,17 @@ uint32_t raster_max_items(const FrameParams& fp, uint64_t pairs, uint32_t split_
 void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER_* if uniform over the flush, else -1 */, const TriRec* recs, const uint32_t* vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
                    const DevTexture* tex, DevStats* stats, uint32_t split_len, uint32_t max_items, uint32_t* items,
-                   uint32_t* n_items, unsigned long long* item_stats) {
+                   uint32_t* n_items, unsigned long long* item_stats, hipEvent_t ev_before, hipEvent_t ev_after) {
     const int tiles = (fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x;
-    if (tiles <= 0) return;
+    if (tiles <= 0) {
+        if (ev_before) (void)hipEventRecord(ev_before, s);
+        if (ev_after) (void)hipEventRecord(ev_after, s);
+        return;
+    }
     (void)hipMemsetAsync(n_items, 0, 4, s);
     hipLaunchKernelGGL(k_make_items, dim3((tiles + 255) / 256), dim3(256), 0, s, fp, tile_start, tile_end, split_len, items, n_items);
     dim3 grid((max_items + TRGL_WAVES_PER_BLOCK - 1) / TRGL_WAVES_PER_BLOCK);
+    if (ev_before) (void)hipEventRecord(ev_before, s);
 #define TRGL_LAUNCH_RASTER(K) hipLaunchKernelGGL(k_raster<K>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items, item_stats)
     switch (kind) {
     case TRGL_SHADER_FLAT:    TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT); break;
@@ -767,6 +839,7 @@ void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER
     default:                  TRGL_LAUNCH_RASTER(KIND_ANY); break;
     }
 #undef TRGL_LAUNCH_RASTER
+    if (ev_after) (void)hipEventRecord(ev_after, s);
     hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(1024), 0, s, stats, n_items, item_stats);
 }
 

@@ -25,7 +25,8 @@ uint32_t raster_max_items(const FrameParams& fp, uint64_t pairs, uint32_t split_
 void launch_raster(hipStream_t s, const FrameParams& fp, int kind, const TriRec* recs, const uint32_t* vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
                    const DevTexture* tex, DevStats* stats, uint32_t split_len, uint32_t max_items, uint32_t* items,
-                   uint32_t* n_items, unsigned long long* item_stats);
+                   uint32_t* n_items, unsigned long long* item_stats, hipEvent_t ev_before = nullptr,
+                   hipEvent_t ev_after = nullptr);     // optional events recorded right around the k_raster launch
 
 void launch_vertex_stage(hipStream_t s, const double mv[16], const double proj[16], const double* vertices, int stride,
                          const uint32_t* indices, uint32_t nfaces, double* clip, double* vary);

@@ -65,8 +65,8 @@ struct trgl_ctx {
     uint64_t last_tris = 0, last_pairs = 0;
 
     bool profiling = false, events_pending = false;
-    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-    double phase_ms[TRGL_NUM_PHASES] = { 0, 0, 0, 0 };
+    hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    double phase_ms[TRGL_NUM_PHASES] = { 0, 0, 0, 0, 0 };
     uint64_t flushes_timed = 0;
 
     std::string err;
@@ -156,7 +156,7 @@ int trgl_create(int device, int width, int height, int bpp, trgl_ctx** out) {
     CRE(hipHostMalloc((void**)&c->draws_pinned, sizeof(DrawDesc) * TRGL_MAX_DRAWS));
     CRE(hipMalloc((void**)&c->stats_dev, sizeof(DevStats)));
     CRE(hipHostMalloc((void**)&c->stats_pinned, sizeof(DevStats)));
-    for (int i = 0; i < 4; ++i) CRE(hipEventCreate(&c->ev[i]));
+    for (int i = 0; i < 6; ++i) CRE(hipEventCreate(&c->ev[i]));
 #undef CRE
     // init_viewport(0,0,W,H), our_gl.cpp:59-69
     trgl_init_viewport(c, 0, 0, width, height);
@@ -176,7 +176,7 @@ int trgl_destroy(trgl_ctx* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->draws_pinned) (void)hipHostFree(c->draws_pinned);
     if (c->stats_pinned) (void)hipHostFree(c->stats_pinned);
-    for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return TRGL_OK;
@@ -387,6 +387,7 @@ static int resolve_events(trgl_ctx* c) {
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->phase_ms[TRGL_PHASE_BIN] += ms;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->phase_ms[TRGL_PHASE_RASTER] += ms;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); c->phase_ms[TRGL_PHASE_TOTAL] += ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[5])); c->phase_ms[TRGL_PHASE_RASTER_KERNEL] += ms;
     c->flushes_timed++;
     c->events_pending = false;
     return TRGL_OK;
@@ -483,7 +484,8 @@ int trgl_flush(trgl_ctx* c) {
     if ((r = grow(c, c->items, c->cap_items, (size_t)max_items + 64))) return r;
     if ((r = grow(c, c->item_stats, c->cap_item_stats, ((size_t)max_items + 64) * 4))) return r;
     launch_raster(s, fp, flush_kind, recs_arg, vals_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev,
-                  split_len, max_items, c->items, c->n_items, c->item_stats);
+                  split_len, max_items, c->items, c->n_items, c->item_stats,
+                  c->profiling ? c->ev[4] : nullptr, c->profiling ? c->ev[5] : nullptr);
     if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[3], s)); c->events_pending = true; }
     HIPCHK(c, hipGetLastError());
 
