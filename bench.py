@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--triangles", type=int, default=10_000_000)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="triangles timed on the host CPU (0 = skip)")
+    ap.add_argument("--writeout-frames", type=int, default=20,
+                    help="clear-only frames timed after the run for the write-out figure (0 = skip, e.g. under rocprofv3 so "
+                         "that the k_raster statistics hold the full launches only)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL strip-gather path even with one rank (rehearsal)")
     ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3"],
                     help="c4 (default, the metric's config): 10 M random flat triangles; c2/c3: PHONG head stand-in at 2048/4096")
@@ -148,9 +151,9 @@ def main():
     # frame write-out alone (outside the timed region): clear + flush with no triangles = k_raster storing W*H*(8+bpp)
     # bytes once; BASELINE north_star's ">= 50 % of HBM roofline on framebuffer + z writes" is this figure
     writeout = None
-    if world == 1:
+    if world == 1 and args.writeout_frames > 0:
         ctx.reset_phase_ms()
-        for _ in range(20):
+        for _ in range(args.writeout_frames):
             ctx.clear()
             ctx.flush()
         wo_ms, wo_n = ctx.phase_ms()

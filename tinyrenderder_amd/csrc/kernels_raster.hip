@@ -243,7 +243,9 @@ struct TileState {
 #ifdef TRGL_DEBUG_COUNTERS
     unsigned long long dbg[8];
 #endif
-    int lane, px0, xa1, ya0, ya1;
+    int lane, px0, py0, xa1, ya0, ya1;
+    double lxm, lym;        // (lane&7) + 0.5 - 2^51 and (lane>>3) + 0.5 - 2^51: pixel centre = (2^51 + block origin) + this, exactly
+    int lrow, lsw;          // (lane>>3)*32 + (lane&7) and ((lane>>3)&3)<<3: the lane's part of lds_index() inside an aligned block
     double* zt; uint32_t* ct;
     uint32_t frags; double zmin, zmax; bool zero_locked;
 };
@@ -262,30 +264,42 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                                                 const DrawDesc* __restrict__ draws,
                                                 const DevTexture* __restrict__ tex, DevStats* __restrict__ stats) {
     constexpr bool FLAT_ONLY = KIND == TRGL_SHADER_FLAT;
-    const int lane = S.lane;
     const double uz = T.uz, ruz = T.ruz;
-    const int x0 = max((int)(T.bb0 & 0xffff), S.px0), x1 = min((int)(T.bb1 & 0xffff), S.xa1);
-    const int y0 = max((int)(T.bb0 >> 16), S.ya0), y1 = min((int)(T.bb1 >> 16), S.ya1);
-    uint32_t blocks = T.blocks;
-    for (int by = y0; by <= y1; by += 8) {
-        for (int bx = x0; bx <= x1; bx += 8, blocks >>= 1) {
-            const int x = bx + (lane & 7), y = by + (lane >> 3);
-            const bool act = (x <= x1) && (y <= y1);
+    // the clamped bbox relative to the tile origin (0..31)
+    const int rx0 = max((int)(T.bb0 & 0xffff), S.px0) - S.px0, rx1 = min((int)(T.bb1 & 0xffff), S.xa1) - S.px0;
+    const int ry0 = max((int)(T.bb0 >> 16), S.ya0) - S.py0, ry1 = min((int)(T.bb1 >> 16), S.ya1) - S.py0;
+    // The scan walks the tile's ALIGNED 8x8 blocks named by T.blocks (bit 4*cy+cx), one pixel per lane.  Which lanes
+    // of a block lie inside the bbox is a product of a column mask and a row mask, both built with scalar
+    // instructions and turned into the predicate without touching the vector ALU.
 #ifdef TRGL_DEBUG_COUNTERS
-            if (!(blocks & 1u)) {                                              // a block the mask calls empty must be empty
-                TRGL_DBG(6, 1);
-                const double pxd = (double)x + 0.5, pyd = (double)y + 0.5, a0 = T.ax - pxd, a1 = T.ay - pyd;
-                const double vx = T.s0y * a1 - a0 * T.s1y, vy = a0 * T.s1x - T.s0x * a1;
-                if (__ballot(act && !(vx + vy < uz) && !(vy > 0.0) && !(vx > 0.0))) TRGL_DBG(7, 1);
-            }
+    uint32_t m = 0;                                              // diagnostic build: every block of the bbox runs, and a
+    for (int cy = ry0 >> 3; cy <= (ry1 >> 3); ++cy)               // block the mask dropped must not write anything
+        for (int cx = rx0 >> 3; cx <= (rx1 >> 3); ++cx) m |= 1u << (4 * cy + cx);
+#else
+    uint32_t m = T.blocks;
 #endif
-            if (!(blocks & 1u)) continue;
+    while (m) {
+        {
+            const int k = __builtin_ctz(m);
+            m &= m - 1;
+            const int cx = k & 3, cy = k >> 2;
+#ifdef TRGL_DEBUG_COUNTERS
+            const bool dropped = !((T.blocks >> k) & 1u);
+            if (dropped) TRGL_DBG(6, 1);
+#endif
+            const int ca = max(rx0 - 8 * cx, 0), cb = min(rx1 - 8 * cx, 7), ra = max(ry0 - 8 * cy, 0), rb = min(ry1 - 8 * cy, 7);
+            const uint32_t colm = (((2u << cb) - (1u << ca)) & 0xffu) * 0x01010101u;
+            const unsigned long long rowm = (~0ull >> (56 - 8 * rb)) & (~0ull << (8 * ra));
+            const bool act = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)colm | ((unsigned long long)colm << 32)) & rowm);
+            const int bx = S.px0 + 8 * cx, by = S.py0 + 8 * cy;
             TRGL_DBG(1, 1);                                                    // blocks entering the coverage test
 #ifdef TRGL_DEBUG_COUNTERS
-            if (WELL_SCALED && __ballot(act && T.zbound < S.zt[lds_index(x, y)]) == 0) TRGL_DBG(5, 1);   // no lane of the block could pass
+            if (WELL_SCALED && __ballot(act && T.zbound < S.zt[(256 * cy + S.lrow) + ((8 * cx) ^ S.lsw)]) == 0) TRGL_DBG(5, 1);   // no lane of the block could pass
 #endif
+            // pixel centre (x+0.5, y+0.5), our_gl.cpp:149: (2^51 + bx) + (lx + 0.5 - 2^51) is exact
+            const double pxc = __hiloint2double(0x43200000, bx << 1) + S.lxm;
+            const double pyc = __hiloint2double(0x43200000, by << 1) + S.lym;
             // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
-            const double pxc = (double)x + 0.5, pyc = (double)y + 0.5;        // :149
             const double s0z = T.ax - pxc, s1z = T.ay - pyc;
             const double ux = T.s0y * s1z - s0z * T.s1y;                      // geometry.h:145
             const double uy = s0z * T.s1x - T.s0x * s1z;                      // geometry.h:146
@@ -305,7 +319,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
             }
             if (__ballot(cov)) TRGL_DBG(2, 1);                                 // blocks with coverage
             if (cov) {
-                const int li = lds_index(x, y);
+                const int li = (256 * cy + S.lrow) + ((8 * cx) ^ S.lsw);   // = lds_index(x, y) for an aligned block
                 const double zold = S.zt[li];
                 if (__ballot(!WELL_SCALED || T.zbound < zold)) TRGL_DBG(3, 1); // blocks that reach the divisions
                 // early z, exact: every covered pixel of this triangle has z >= T.zbound (see the hierarchical-Z
@@ -347,6 +361,9 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                             }
                         }
                     }
+#ifdef TRGL_DEBUG_COUNTERS
+                    if (dropped) TRGL_DBG(7, 1);                              // must stay 0
+#endif
                     S.zt[li] = z;                                             // :191
                     S.ct[li] = color;                                         // :192
                     ++S.frags;                                                // :194
@@ -356,6 +373,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                     if ((z < S.zmin) || (S.zmax < z)) {
                         S.zmin = dmin(S.zmin, z); S.zmax = dmax(S.zmax, z);
                         if (z == 0.0 && !S.zero_locked) {
+                            const int x = bx + (S.lane & 7), y = by + (S.lane >> 3);
                             unsigned long long order = ((unsigned long long)T.tri << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
                             atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
                         }
@@ -501,7 +519,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #ifdef TRGL_DEBUG_COUNTERS
     for (int k = 0; k < 8; ++k) S.dbg[k] = 0;
 #endif
-    S.lane = lane; S.px0 = px0; S.xa1 = xa1; S.ya0 = ya0; S.ya1 = ya1; S.zt = zt; S.ct = ct;
+    S.lane = lane; S.px0 = px0; S.py0 = py0; S.xa1 = xa1; S.ya0 = ya0; S.ya1 = ya1; S.zt = zt; S.ct = ct;
+    S.lxm = ((double)(lane & 7) + 0.5) - 0x1p51; S.lym = ((double)(lane >> 3) + 0.5) - 0x1p51;
+    S.lrow = (lane >> 3) * 32 + (lane & 7); S.lsw = ((lane >> 3) & 3) << 3;
     S.frags = 0; S.zmin = __builtin_inf(); S.zmax = -__builtin_inf();
     S.zero_locked = stats->zero_locked != 0;
 
@@ -529,26 +549,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             uint32_t p = bs + 64 + lane;
             nxt = load_rec(recs, vals[p < end ? p : end - 1], true);
         }
-        // ---- hierarchical Z, once per batch of 64 list entries -------------------------------------------------
-        // Lane l owns the 4x4-pixel cell (l&7, l>>3) of the tile and publishes the maximum depth currently stored
-        // in it.  Then every lane tests ITS OWN triangle of the batch: for a well-scaled triangle each covered
-        // pixel has b_i >= 0 and b0+b1+b2 = 1 +- 2^-50, so the interpolated depth (our_gl.cpp:156-158) is
-        //   z >= min(z0,z1,z2) - 2^-49 * max|z_i|      (rounding included; the margin below is 2^-40),
-        // and the z-test is a strict `<` (our_gl.cpp:165): if that bound is >= the maximum of every cell its bbox
-        // touches, no pixel can pass and the triangle is skipped before its constants are even broadcast.
-        // Cell maxima only fall while a batch is rasterized, so values from the batch start stay valid bounds.
-        // (Finer variants lost: a dead-block mask per triangle skipped only 10 % more blocks — triangles that
-        // survive have a low bound, so their blocks are rarely dead — and its per-lane loop cost 0.5 ms.)
+        // ---- block masks, once per batch of 64 list entries ----------------------------------------------------
+        // Lane l owns the 4x4-pixel cell (l&7, l>>3) of the tile and reduces the depths currently stored in it (rows
+        // and columns this item does not own count as -inf: they are never scanned); 16 lanes then publish the
+        // maxima of the 16 aligned 8x8 blocks.  Cell maxima only fall while a batch is rasterized, so the values
+        // of the batch start stay valid upper bounds.
+        //
+        // Then every lane decides, for ITS OWN triangle of the batch, which aligned 8x8 blocks of the tile have to be
+        // scanned at all.  Block k is dropped when
+        //  (edges)  one of the three edge functions excludes all of it: a pixel is covered iff the rounded u.x <= 0,
+        //           u.y <= 0 and u.x+u.y >= u.z (raster_triangle); each is affine in the pixel centre, so its extreme
+        //           over the block sits at the corner the gradient's signs select;
+        //  (depth)  no covered pixel of it can pass the strict z-test (our_gl.cpp:165): every covered pixel has
+        //           b_i >= 0 and b0+b1+b2 = 1 +- 2^-50, hence z >= zbound = min(z0,z1,z2) - 2^-40 max|z_i|; and the
+        //           computed z (our_gl.cpp:156-158) differs from the depth plane z0 + (u.y/u.z)(z1-z0) + (u.x/u.z)(z2-z0)
+        //           by at most 2^-50 max|z_i| (R S/|u.z| + 1)  [R >= |A - pixel| on the tile, S = sum of |edge deltas|:
+        //           the roundings of u.x, u.y, their quotients and the weighted sum], so z >= plane minimum over the
+        //           block - that; if the larger of the two bounds is >= the block's stored maximum, nothing passes.
+        // Corner values are stepped block to block; those roundings and a mis-chosen corner of a nearly flat function
+        // are of the same 2^-50 order, and every test keeps a 2^-40 margin.  NaN/inf compare false = "keep".
+        // A triangle with no block left is skipped before its constants are broadcast.  On C4 this leaves 0.5x list
+        // entries and 0.6x blocks of what a bbox scan with a per-triangle depth bound visits
+        // (profiles/raster_counters.py; the diagnostic build checks that no dropped block would have written).
         {
             const int cx = lane & 7, cy = lane >> 3;
             double m = -__builtin_inf();
 #pragma unroll
-            for (int dy = 0; dy < 4; ++dy)
+            for (int dy = 0; dy < 4; ++dy) {
+                const bool row_owned = (py0 + 4 * cy + dy >= ya0) && (py0 + 4 * cy + dy <= ya1) && (px0 + 4 * cx <= xa1);
 #pragma unroll
-                for (int dx = 0; dx < 4; ++dx) m = dmax(m, zt[lds_index(4 * cx + dx, 4 * cy + dy)]);
+                for (int dx = 0; dx < 4; ++dx) {
+                    const double v = zt[lds_index(4 * cx + dx, 4 * cy + dy)];
+                    m = dmax(m, row_owned ? v : -__builtin_inf());
+                }
+            }
             hz[lane] = m;
             __builtin_amdgcn_wave_barrier();
-            // coarse level: 8x8-pixel cells (4x4 of them), for triangles whose bbox spans more than 16 fine cells
             if (lane < 16) {
                 const int f = (lane >> 2) * 16 + (lane & 3) * 2;
                 hz[64 + lane] = dmax(dmax(hz[f], hz[f + 1]), dmax(hz[f + 8], hz[f + 9]));
@@ -557,69 +593,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         unsigned long long todo;
         double zbound_l = -__builtin_inf();       // this lane's triangle: lower bound of its covered depths
-        uint32_t blocks_l = 0xffffu;              // ... and which blocks of its scan can hold covered pixels
+        uint32_t blocks_l = 0;                    // ... and the aligned 8x8 blocks of the tile its scan has to visit
         {
             const int bx0 = (int)(cur.q[7].x & 0xffff), by0 = (int)(cur.q[7].x >> 16);
             const int bx1 = (int)(cur.q[7].y & 0xffff), by1 = (int)(cur.q[7].y >> 16);
             const int x0 = max(bx0, px0), x1 = min(bx1, xa1), y0 = max(by0, ya0), y1 = min(by1, ya1);
             bool skip = (uint32_t)lane >= nbatch || x0 > x1 || y0 > y1;      // not in the list / misses this band
             const double ruz_l = __hiloint2double((int)cur.q[3].w, (int)cur.q[3].z);
-            if (!skip && ruz_l != 0.0) {
-                const double z0 = __hiloint2double((int)cur.q[4].y, (int)cur.q[4].x);
-                const double z1 = __hiloint2double((int)cur.q[4].w, (int)cur.q[4].z);
-                const double z2 = __hiloint2double((int)cur.q[5].y, (int)cur.q[5].x);
-                const double zlo = dmin(dmin(z0, z1), z2), zabs = dmax(dmax(fabs(z0), fabs(z1)), fabs(z2));
-                const double zbound = zlo - zabs * 0x1p-40;
-                zbound_l = zbound;
-                const int cx0 = (x0 & 31) >> 2, cx1 = (x1 & 31) >> 2, cy0 = (y0 & 31) >> 2, cy1 = (y1 & 31) >> 2;
-                bool behind = true;
-                if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= 16) {
-                    for (int cyy = cy0; cyy <= cy1 && behind; ++cyy)
-                        for (int cxx = cx0; cxx <= cx1; ++cxx)
-                            if (!(zbound >= hz[cyy * 8 + cxx])) { behind = false; break; }
+            if (!skip) {
+                const int c0 = (x0 - px0) >> 3, c1 = (x1 - px0) >> 3, r0 = (y0 - py0) >> 3, r1 = (y1 - py0) >> 3;
+                if (ruz_l == 0.0) {                // not well scaled: the literal path scans every block of the bbox
+                    blocks_l = (((2u << c1) - (1u << c0)) & 0xfu) * 0x1111u & ((0xffffu >> (12 - 4 * r1)) & (0xffffu << (4 * r0)));
                 } else {
-                    for (int cyy = cy0 >> 1; cyy <= (cy1 >> 1) && behind; ++cyy)
-                        for (int cxx = cx0 >> 1; cxx <= (cx1 >> 1); ++cxx)
-                            if (!(zbound >= hz[64 + cyy * 4 + cxx])) { behind = false; break; }
-                }
-                skip = behind;
-                if (!behind) {
-                    // Which 8x8 blocks of the scan can hold covered pixels at all?  A pixel is covered iff the rounded
-                    // u.x <= 0, u.y <= 0 and u.x+u.y >= u.z (raster_triangle); each is an affine function of the pixel
-                    // centre, so over a block its extreme sits at a corner chosen by the gradient's signs.  The corner
-                    // values are stepped block to block; every rounding involved (here and in the per-pixel
-                    // evaluation) is below 2^-48 * (|a|+|b|) * R, R bounding |A - pixel| on the tile, and the test
-                    // keeps a margin of 2^-40 of that: a block is dropped only when one edge excludes all of it.
+                    const double z0 = __hiloint2double((int)cur.q[4].y, (int)cur.q[4].x);
+                    const double z1 = __hiloint2double((int)cur.q[4].w, (int)cur.q[4].z);
+                    const double z2 = __hiloint2double((int)cur.q[5].y, (int)cur.q[5].x);
+                    const double zlo = dmin(dmin(z0, z1), z2), zabs = dmax(dmax(fabs(z0), fabs(z1)), fabs(z2));
+                    const double zbound = zlo - zabs * 0x1p-40;
+                    zbound_l = zbound;
                     const double ax = __hiloint2double((int)cur.q[0].y, (int)cur.q[0].x), ay = __hiloint2double((int)cur.q[0].w, (int)cur.q[0].z);
                     const double s0x = __hiloint2double((int)cur.q[1].y, (int)cur.q[1].x), s0y = __hiloint2double((int)cur.q[1].w, (int)cur.q[1].z);
                     const double s1x = __hiloint2double((int)cur.q[2].y, (int)cur.q[2].x), s1y = __hiloint2double((int)cur.q[2].w, (int)cur.q[2].z);
                     const double uz_l = __hiloint2double((int)cur.q[3].y, (int)cur.q[3].x);
-                    const double X0 = (double)x0 + 0.5, Y0 = (double)y0 + 0.5;
-                    const double gx = s1y - s1x, gy = s0x - s0y;
-                    const double dxa = ax - (X0 + (s1y >= 0.0 ? 0.0 : 7.0)), dya = ay - (Y0 + (s0y <= 0.0 ? 0.0 : 7.0));   // min of u.x
-                    const double dxb = ax - (X0 + (s1x <= 0.0 ? 0.0 : 7.0)), dyb = ay - (Y0 + (s0x >= 0.0 ? 0.0 : 7.0));   // min of u.y
-                    const double dxc = ax - (X0 + (gx >= 0.0 ? 7.0 : 0.0)), dyc = ay - (Y0 + (gy >= 0.0 ? 7.0 : 0.0));     // max of u.x+u.y
-                    double fa_row = s0y * dya - dxa * s1y;
-                    double fb_row = dxb * s1x - s0x * dyb;
-                    double fc_row = (s0y * dyc - dxc * s1y) + (dxc * s1x - s0x * dyc);
-                    const double R = fabs(ax - X0) + fabs(ay - Y0) + 64.0;
-                    const double ma = 0x1p-40 * ((fabs(s0y) + fabs(s1y)) * R), mb = 0x1p-40 * ((fabs(s0x) + fabs(s1x)) * R);
+                    // centre of the low corner pixel of block (c0, r0)
+                    const double X0 = (double)(px0 + 8 * c0) + 0.5, Y0 = (double)(py0 + 8 * r0) + 0.5;
+                    const double dx0 = ax - X0, dy0 = ay - Y0;
+                    // edge functions: u.x = s0y (ay-Y) - (ax-X) s1y, u.y = (ax-X) s1x - s0x (ay-Y), u.x + u.y
+                    const double gx = s1y - s1x, gy = s0x - s0y;                          // gradient of u.x + u.y
+                    const double oxa = s1y >= 0.0 ? 0.0 : 7.0, oya = s0y <= 0.0 ? 0.0 : 7.0;    // corner of min u.x
+                    const double oxb = s1x <= 0.0 ? 0.0 : 7.0, oyb = s0x >= 0.0 ? 0.0 : 7.0;    // corner of min u.y
+                    const double oxc = gx >= 0.0 ? 7.0 : 0.0, oyc = gy >= 0.0 ? 7.0 : 0.0;      // corner of max u.x+u.y
+                    double fa_row = s0y * (dy0 - oya) - (dx0 - oxa) * s1y;
+                    double fb_row = (dx0 - oxb) * s1x - s0x * (dy0 - oyb);
+                    double fc_row = (s0y * (dy0 - oyc) - (dx0 - oxc) * s1y) + ((dx0 - oxc) * s1x - s0x * (dy0 - oyc));
+                    const double R = fabs(dx0) + fabs(dy0) + 64.0;
+                    const double Sa = fabs(s0y) + fabs(s1y), Sb = fabs(s0x) + fabs(s1x);
+                    const double ma = 0x1p-40 * (Sa * R), mb = 0x1p-40 * (Sb * R);
                     const double lim_c = uz_l - (ma + mb);
+                    // depth plane: z0 + (u.y/u.z) dz1 + (u.x/u.z) dz2, minimum corner by the gradient's signs
+                    const double dz1 = z1 - z0, dz2 = z2 - z0;
+                    const double gzx = (s1y * dz2 - s1x * dz1) * ruz_l, gzy = (s0x * dz1 - s0y * dz2) * ruz_l;
+                    const double ux0 = s0y * dy0 - dx0 * s1y, uy0 = dx0 * s1x - s0x * dy0;
+                    const double mz = 0x1p-40 * (zabs * ((R * (Sa + Sb)) * fabs(ruz_l) + 1.0));
+                    double fz_row = ((z0 + (uy0 * ruz_l) * dz1) + (ux0 * ruz_l) * dz2) + ((gzx >= 0.0 ? 0.0 : 7.0) * gzx + (gzy >= 0.0 ? 0.0 : 7.0) * gzy) - mz;
                     const double sax = 8.0 * s1y, say = -8.0 * s0y, sbx = -8.0 * s1x, sby = 8.0 * s0x, scx = 8.0 * gx, scy = 8.0 * gy;
-                    const int nbx = ((x1 - x0) >> 3) + 1, nby = ((y1 - y0) >> 3) + 1;
-                    uint32_t m = 0, bit = 1;
-                    for (int iy = 0; iy < nby; ++iy) {
-                        double fa = fa_row, fb = fb_row, fc = fc_row;
-                        for (int ix = 0; ix < nbx; ++ix) {
-                            if (!(fa > ma || fb > mb || fc < lim_c)) m |= bit;
-                            bit <<= 1;
-                            fa += sax; fb += sbx; fc += scx;
+                    const double szx = 8.0 * gzx, szy = 8.0 * gzy;
+                    uint32_t mk = 0;
+                    for (int r = r0; r <= r1; ++r) {
+                        double fa = fa_row, fb = fb_row, fc = fc_row, fz = fz_row;
+                        for (int c = c0; c <= c1; ++c) {
+                            const double top = hz[64 + 4 * r + c];
+                            const bool outside = fa > ma || fb > mb || fc < lim_c;
+                            const bool behind = fz >= top || zbound >= top;
+                            if (!(outside || behind)) mk |= 1u << (4 * r + c);
+                            fa += sax; fb += sbx; fc += scx; fz += szx;
                         }
-                        fa_row += say; fb_row += sby; fc_row += scy;
+                        fa_row += say; fb_row += sby; fc_row += scy; fz_row += szy;
                     }
-                    blocks_l = m;
-                    skip = m == 0;
+                    blocks_l = mk;
                 }
+                skip = blocks_l == 0;
             }
             todo = __ballot(!skip);
             if (HAS_V && !skip) {        // this lane's triangle will be rasterized: fetch its varyings now
