@@ -268,9 +268,9 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
     // the clamped bbox relative to the tile origin (0..31)
     const int rx0 = max((int)(T.bb0 & 0xffff), S.px0) - S.px0, rx1 = min((int)(T.bb1 & 0xffff), S.xa1) - S.px0;
     const int ry0 = max((int)(T.bb0 >> 16), S.ya0) - S.py0, ry1 = min((int)(T.bb1 >> 16), S.ya1) - S.py0;
-    // The scan walks the tile's ALIGNED 8x8 blocks named by T.blocks (bit 4*cy+cx), one pixel per lane.  Which lanes
-    // of a block lie inside the bbox is a product of a column mask and a row mask, both built with scalar
-    // instructions and turned into the predicate without touching the vector ALU.
+    // The scan walks the tile's ALIGNED 8x8 blocks named by T.blocks (bit 4*cy+cx), one pixel per lane.  The kernel
+    // issues about one instruction per SIMD issue slot whatever its type (PMC: VALU + SALU + branch counts vs slots),
+    // so scalar bookkeeping per block is kept as short as the vector part.
 #ifdef TRGL_DEBUG_COUNTERS
     uint32_t m = 0;                                              // diagnostic build: every block of the bbox runs, and a
     for (int cy = ry0 >> 3; cy <= (ry1 >> 3); ++cy)               // block the mask dropped must not write anything
@@ -287,10 +287,9 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
             const bool dropped = !((T.blocks >> k) & 1u);
             if (dropped) TRGL_DBG(6, 1);
 #endif
-            const int ca = max(rx0 - 8 * cx, 0), cb = min(rx1 - 8 * cx, 7), ra = max(ry0 - 8 * cy, 0), rb = min(ry1 - 8 * cy, 7);
-            const uint32_t colm = (((2u << cb) - (1u << ca)) & 0xffu) * 0x01010101u;
-            const unsigned long long rowm = (~0ull >> (56 - 8 * rb)) & (~0ull << (8 * ra));
-            const bool act = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)colm | ((unsigned long long)colm << 32)) & rowm);
+            // lanes of the block inside the clamped bbox: one unsigned compare per axis (a negative difference wraps)
+            const bool act = (uint32_t)((S.lane & 7) + (8 * cx - rx0)) <= (uint32_t)(rx1 - rx0) &&
+                             (uint32_t)((S.lane >> 3) + (8 * cy - ry0)) <= (uint32_t)(ry1 - ry0);
             const int bx = S.px0 + 8 * cx, by = S.py0 + 8 * cy;
             TRGL_DBG(1, 1);                                                    // blocks entering the coverage test
 #ifdef TRGL_DEBUG_COUNTERS
