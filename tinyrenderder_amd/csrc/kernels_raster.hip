@@ -230,7 +230,7 @@ __device__ __forceinline__ double div_by_uz(double a, double uz, double ruz) {
 struct TriConst {
     double ax, ay, s0x, s0y, s1x, s1y, uz, ruz, z0, z1, z2, iw0, iw1, iw2;
     double zbound;      // lower bound of the depth of any covered pixel (-inf if the triangle is not well scaled)
-    uint32_t bb0, bb1, color, dl, tri;
+    uint32_t rbox, color, dl;   // rbox: rx0 | ry0<<8 | (rx1-rx0)<<16 | (ry1-ry0)<<24, the clamped bbox relative to the tile origin
     uint32_t blocks;    // bit k set: the k-th 8x8 block of the scan (row-major from the clamped bbox corner) may hold covered pixels
 };
 // Per-wave tile state.
@@ -260,14 +260,14 @@ constexpr int KIND_ANY = 4;
 struct VaryQ { uint4 v[2]; uint32_t color; };       // GOURAUD: three intensities + the base colour of lane j's triangle
 
 template <int KIND, bool WELL_SCALED>
-__device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& V, uint32_t j, TileState& S,
+__device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& V, uint32_t tri_l, uint32_t j, TileState& S,
                                                 const DrawDesc* __restrict__ draws,
                                                 const DevTexture* __restrict__ tex, DevStats* __restrict__ stats) {
     constexpr bool FLAT_ONLY = KIND == TRGL_SHADER_FLAT;
     const double uz = T.uz, ruz = T.ruz;
-    // the clamped bbox relative to the tile origin (0..31)
-    const int rx0 = max((int)(T.bb0 & 0xffff), S.px0) - S.px0, rx1 = min((int)(T.bb1 & 0xffff), S.xa1) - S.px0;
-    const int ry0 = max((int)(T.bb0 >> 16), S.ya0) - S.py0, ry1 = min((int)(T.bb1 >> 16), S.ya1) - S.py0;
+    // the clamped bbox relative to the tile origin (0..31), from the batch phase
+    const int rx0 = (int)(T.rbox & 0xff), ry0 = (int)((T.rbox >> 8) & 0xff);
+    const int rx1 = rx0 + (int)((T.rbox >> 16) & 0xff), ry1 = ry0 + (int)(T.rbox >> 24);
     // The scan walks the tile's ALIGNED 8x8 blocks named by T.blocks (bit 4*cy+cx), one pixel per lane.  The kernel
     // issues about one instruction per SIMD issue slot whatever its type (PMC: VALU + SALU + branch counts vs slots),
     // so scalar bookkeeping per block is kept as short as the vector part.
@@ -276,9 +276,9 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
     for (int cy = ry0 >> 3; cy <= (ry1 >> 3); ++cy)               // block the mask dropped must not write anything
         for (int cx = rx0 >> 3; cx <= (rx1 >> 3); ++cx) m |= 1u << (4 * cy + cx);
 #else
-    uint32_t m = T.blocks;
+    uint32_t m = T.blocks;                                        // never 0: such triangles are not broadcast
 #endif
-    while (m) {
+    do {
         {
             const int k = __builtin_ctz(m);
             m &= m - 1;
@@ -373,7 +373,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                         S.zmin = dmin(S.zmin, z); S.zmax = dmax(S.zmax, z);
                         if (z == 0.0 && !S.zero_locked) {
                             const int x = bx + (S.lane & 7), y = by + (S.lane >> 3);
-                            unsigned long long order = ((unsigned long long)T.tri << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
+                            unsigned long long order = ((unsigned long long)bcast_u(tri_l, j) << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
                             atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
                         }
                     }
@@ -381,7 +381,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                 }
             }
         }
-    }
+    } while (m);
 }
 
 // Tile out: row-contiguous stores of the wave's rows [ya0, ya1] x columns [px0, xa1].  CLEARED: the item has no
@@ -593,6 +593,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         unsigned long long todo;
         double zbound_l = -__builtin_inf();       // this lane's triangle: lower bound of its covered depths
         uint32_t blocks_l = 0;                    // ... and the aligned 8x8 blocks of the tile its scan has to visit
+        uint32_t rbox_l = 0;                      // ... and its clamped bbox relative to the tile origin (TriConst::rbox)
         {
             const int bx0 = (int)(cur.q[7].x & 0xffff), by0 = (int)(cur.q[7].x >> 16);
             const int bx1 = (int)(cur.q[7].y & 0xffff), by1 = (int)(cur.q[7].y >> 16);
@@ -600,6 +601,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             bool skip = (uint32_t)lane >= nbatch || x0 > x1 || y0 > y1;      // not in the list / misses this band
             const double ruz_l = __hiloint2double((int)cur.q[3].w, (int)cur.q[3].z);
             if (!skip) {
+                rbox_l = (uint32_t)(x0 - px0) | ((uint32_t)(y0 - py0) << 8) | ((uint32_t)(x1 - x0) << 16) | ((uint32_t)(y1 - y0) << 24);
                 const int c0 = (x0 - px0) >> 3, c1 = (x1 - px0) >> 3, r0 = (y0 - py0) >> 3, r1 = (y1 - py0) >> 3;
                 if (ruz_l == 0.0) {                // not well scaled: the literal path scans every block of the bbox
                     blocks_l = (((2u << c1) - (1u << c0)) & 0xfu) * 0x1111u & ((0xffffu >> (12 - 4 * r1)) & (0xffffu << (4 * r0)));
@@ -679,12 +681,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 T.iw0 = bcast_d(cur.q[5].z, cur.q[5].w, j); T.iw1 = bcast_d(cur.q[6].x, cur.q[6].y, j);
                 T.iw2 = bcast_d(cur.q[6].z, cur.q[6].w, j); T.dl = bcast_u(cur.q[7].w, j);
             }
-            T.bb0 = bcast_u(cur.q[7].x, j); T.bb1 = bcast_u(cur.q[7].y, j); T.color = bcast_u(cur.q[7].z, j);
-            T.tri = bcast_u(cur.tri, j); T.blocks = bcast_u(blocks_l, j);
+            T.rbox = bcast_u(rbox_l, j); T.color = bcast_u(cur.q[7].z, j);
+            T.blocks = bcast_u(blocks_l, j);
             T.zbound = bcast_d((uint32_t)__double2loint(zbound_l), (uint32_t)__double2hiint(zbound_l), j);
             TRGL_DBG(0, 1);                                                    // list entries rasterized (not skipped)
-            if (T.ruz != 0.0) raster_triangle<KIND, true>(T, V, j, S, draws, tex, stats);    // wave-uniform
-            else raster_triangle<KIND, false>(T, V, j, S, draws, tex, stats);
+            if (T.ruz != 0.0) raster_triangle<KIND, true>(T, V, cur.tri, j, S, draws, tex, stats);    // wave-uniform
+            else raster_triangle<KIND, false>(T, V, cur.tri, j, S, draws, tex, stats);
         }
         if (PREFETCH) cur = nxt;
         else if (bs + 64 < end) {
