@@ -246,7 +246,9 @@ struct TileState {
     int lane, px0, py0, xa1, ya0, ya1;
     double lxm, lym;        // (lane&7) + 0.5 - 2^51 and (lane>>3) + 0.5 - 2^51: pixel centre = (2^51 + block origin) + this, exactly
     int lrow, lsw;          // (lane>>3)*32 + (lane&7) and ((lane>>3)&3)<<3: the lane's part of lds_index() inside an aligned block
-    double* zt; uint32_t* ct;
+    double* zt;
+    uint8_t* fb_lane;       // address of this lane's pixel of block 0 in the framebuffer (colours are written straight to it)
+    int bpp; uint32_t row_bytes;   // framebuffer bytes per pixel / per row
     uint32_t frags; double zmin, zmax; bool zero_locked;
 };
 
@@ -364,7 +366,12 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                     if (dropped) TRGL_DBG(7, 1);                              // must stay 0
 #endif
                     S.zt[li] = z;                                             // :191
-                    S.ct[li] = color;                                         // :192
+                    {                                                         // :192, tgaimage.cpp:32-39: straight to the framebuffer
+                        uint8_t* dst = S.fb_lane + ((size_t)(8 * cy) * S.row_bytes + (size_t)(8 * cx) * S.bpp);
+                        if (S.bpp == 3) { dst[0] = (uint8_t)color; dst[1] = (uint8_t)(color >> 8); dst[2] = (uint8_t)(color >> 16); }
+                        else if (S.bpp == 4) *reinterpret_cast<uint32_t*>(dst) = color;
+                        else for (int i = 0; i < S.bpp; ++i) dst[i] = (uint8_t)(color >> (8 * i));
+                    }
                     ++S.frags;                                                // :194
                     // :197-198.  After a few fragments a lane's running min/max rarely moves, so the updates
                     // live in a branch.  A written zero can only end up as a z-range end if it is a new min or
@@ -388,7 +395,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
 // triangles and starts from the clear values, so they are stored directly (no LDS round trip; this is the whole
 // kernel on a clear-only frame, the "framebuffer + z write-out" figure of BASELINE.json).
 template <bool CLEARED>
-__device__ __forceinline__ void tile_out(const FrameParams& fp, const double* zt, const uint32_t* ct, int lane,
+__device__ __forceinline__ void tile_out_z(const FrameParams& fp, const double* zt, int lane,
                                          int px0, int py0, int xa1, int ya0, int ya1) {
     const bool full_x = (px0 + TRGL_TILE - 1) <= xa1;
     // z: 16 B per lane, 4 rows per store instruction
@@ -406,15 +413,21 @@ __device__ __forceinline__ void tile_out(const FrameParams& fp, const double* zt
             if (x <= xa1 && y >= ya0 && y <= ya1) fp.zb[(size_t)x + (size_t)y * fp.W] = CLEARED ? fp.clear_z : zt[lds_index(x, y)];
         }
     }
+}
+
+// The clear colour of the wave's rows x columns, row-contiguous (12 or 16 B per lane).  Ordinary stores: fragments
+// overwrite these bytes later, preferably while the lines are still in L2.
+__device__ __forceinline__ void tile_clear_color(const FrameParams& fp, int lane, int px0, int py0, int xa1, int ya0, int ya1) {
+    const bool full_x = (px0 + TRGL_TILE - 1) <= xa1;
     // colour: 4 pixels per lane (12 B for RGB, 16 B for RGBA), 8 rows per store instruction
     if (full_x && (fp.W & 3) == 0 && (fp.bpp == 3 || fp.bpp == 4)) {
         for (int r8 = 0; r8 < TRGL_TILE; r8 += 8) {
             int x = px0 + ((lane & 7) << 2), y = py0 + r8 + (lane >> 3);
             if (y >= ya0 && y <= ya1) {
-                uint4 c = CLEARED ? make_uint4(fp.clear_color, fp.clear_color, fp.clear_color, fp.clear_color) : *reinterpret_cast<const uint4*>(&ct[lds_index(x, y)]);
+                const uint4 c = make_uint4(fp.clear_color, fp.clear_color, fp.clear_color, fp.clear_color);
                 size_t idx = (size_t)x + (size_t)y * fp.W;
                 if (fp.bpp == 4) {
-                    { typedef uint32_t nt_u4 __attribute__((ext_vector_type(4))); nt_u4 nv = {c.x, c.y, c.z, c.w}; __builtin_nontemporal_store(nv, reinterpret_cast<nt_u4*>(fp.fb + idx * 4)); }
+                    *reinterpret_cast<uint4*>(fp.fb + idx * 4) = c;
                 } else {
                     uint32_t d0 = (c.x & 0xffffffu) | (c.y << 24);
                     uint32_t d1 = ((c.y >> 8) & 0xffffu) | (c.z << 16);
@@ -428,7 +441,7 @@ __device__ __forceinline__ void tile_out(const FrameParams& fp, const double* zt
         for (int r2 = 0; r2 < TRGL_TILE; r2 += 2) {
             int x = px0 + (lane & 31), y = py0 + r2 + (lane >> 5);
             if (x <= xa1 && y >= ya0 && y <= ya1) {
-                uint32_t c = CLEARED ? fp.clear_color : ct[lds_index(x, y)];
+                const uint32_t c = fp.clear_color;
                 uint8_t* dst = fp.fb + ((size_t)x + (size_t)y * fp.W) * fp.bpp;
                 for (int i = 0; i < fp.bpp; ++i) dst[i] = (uint8_t)(c >> (8 * i));
             }
@@ -438,7 +451,7 @@ __device__ __forceinline__ void tile_out(const FrameParams& fp, const double* zt
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND <= TRGL_SHADER_GOURAUD ? 4 : 3, KIND <= TRGL_SHADER_GOURAUD ? 4 : 3))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
                                                 const uint32_t* __restrict__ tile_start,
                                                 const uint32_t* __restrict__ tile_end,
@@ -447,7 +460,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                 const uint32_t* __restrict__ items, const uint32_t* __restrict__ n_items,
                                                 unsigned long long* __restrict__ item_stats) {
     __shared__ __attribute__((aligned(16))) double   s_z[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
-    __shared__ __attribute__((aligned(16))) uint32_t s_c[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
     __shared__ double s_hz[TRGL_WAVES_PER_BLOCK][80];    // depth maxima of the 64 4x4-pixel cells + 16 8x8-pixel cells
 
     const int lane = threadIdx.x & 63;
@@ -479,9 +491,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 
     double* zt = s_z[w];
-    uint32_t* ct = s_c[w];
     if (fp.init_from_clear && beg == end) {              // cleared and empty: store the clear values, nothing else
-        tile_out<true>(fp, zt, ct, lane, px0, py0, xa1, ya0, ya1);
+        tile_out_z<true>(fp, zt, lane, px0, py0, xa1, ya0, ya1);
+        tile_clear_color(fp, lane, px0, py0, xa1, ya0, ya1);
         if (lane == 0) {
             ulonglong2* dst = reinterpret_cast<ulonglong2*>(item_stats + (size_t)item_idx * 4);
             dst[0] = make_ulonglong2(0ull, ~0ull); dst[1] = make_ulonglong2(0ull, 0ull);
@@ -489,21 +501,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         return;
     }
 
-    // ---- tile in: clear values, or the current framebuffer / z-buffer contents --------------------
+    // ---- tile in -----------------------------------------------------------------------------------------
+    // Depths live in LDS for the whole tile.  Colours do not: a fragment that passes the z-test stores its colour
+    // straight into the framebuffer (TGAImage::set, tgaimage.cpp:32-39).  With aligned blocks the same lane owns a
+    // pixel every time, so successive writes to a pixel are same-thread, same-address stores and keep program order.
+    // 8.6 KB of LDS per wave instead of 12.6 KB = 16 waves per CU instead of 12, and no colour tile in / out.
     if (fp.init_from_clear) {
-        for (int k = lane; k < TRGL_TILE_PIX; k += 64) { zt[k] = fp.clear_z; ct[k] = fp.clear_color; }
+        for (int k = lane; k < TRGL_TILE_PIX; k += 64) zt[k] = fp.clear_z;
+        tile_clear_color(fp, lane, px0, py0, xa1, ya0, ya1);
+        // other lanes wrote these bytes: have the stores acknowledged before any fragment of this wave follows them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         for (int r = 0; r < TRGL_TILE; r += 2) {
             int x = px0 + (lane & 31), y = py0 + r + (lane >> 5);
-            double z = fp.clear_z; uint32_t c = 0;
-            if (x <= xa1 && y >= ya0 && y <= ya1) {
-                size_t idx = (size_t)x + (size_t)y * fp.W;
-                z = fp.zb[idx];
-                const uint8_t* p = fp.fb + idx * fp.bpp;
-                for (int i = 0; i < fp.bpp; ++i) c |= (uint32_t)p[i] << (8 * i);
-            }
-            int li = lds_index(x, y);
-            zt[li] = z; ct[li] = c;
+            double z = fp.clear_z;
+            if (x <= xa1 && y >= ya0 && y <= ya1) z = fp.zb[(size_t)x + (size_t)y * fp.W];
+            zt[lds_index(x, y)] = z;
         }
     }
 
@@ -513,12 +526,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // of fetching them where a block shades (measured: 232 -> <=168 VGPRs).  For the same reason only the cheap kinds
     // keep the next batch of records in flight.
     constexpr bool HAS_V = KIND == TRGL_SHADER_GOURAUD;
-    constexpr bool PREFETCH = KIND == TRGL_SHADER_FLAT || KIND == TRGL_SHADER_GOURAUD;
+    constexpr bool PREFETCH = false;
     TileState S;
 #ifdef TRGL_DEBUG_COUNTERS
     for (int k = 0; k < 8; ++k) S.dbg[k] = 0;
 #endif
-    S.lane = lane; S.px0 = px0; S.py0 = py0; S.xa1 = xa1; S.ya0 = ya0; S.ya1 = ya1; S.zt = zt; S.ct = ct;
+    S.lane = lane; S.px0 = px0; S.py0 = py0; S.xa1 = xa1; S.ya0 = ya0; S.ya1 = ya1; S.zt = zt;
+    S.bpp = fp.bpp; S.row_bytes = (uint32_t)fp.W * (uint32_t)fp.bpp;
+    S.fb_lane = fp.fb + ((size_t)(py0 + (lane >> 3)) * fp.W + (size_t)(px0 + (lane & 7))) * fp.bpp;
     S.lxm = ((double)(lane & 7) + 0.5) - 0x1p51; S.lym = ((double)(lane >> 3) + 0.5) - 0x1p51;
     S.lrow = (lane >> 3) * 32 + (lane & 7); S.lsw = ((lane >> 3) & 3) << 3;
     S.frags = 0; S.zmin = __builtin_inf(); S.zmax = -__builtin_inf();
@@ -702,7 +717,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #endif
 
     // ---- tile out ----------------------------------------------------------------------------
-    tile_out<false>(fp, zt, ct, lane, px0, py0, xa1, ya0, ya1);
+    tile_out_z<false>(fp, zt, lane, px0, py0, xa1, ya0, ya1);
 
     // ---- stats: our_gl.cpp:194-198, reduced per wave, one set of atomics per tile -----------------
     unsigned long long kmin = zkey(zmin), kmax = zkey(zmax);
