@@ -37,7 +37,7 @@ for f in glob.glob(os.path.join(out, "trace_writeout", "**", "*kernel_stats.csv"
                   f"{4096*4096*11.5/avg:.0f} GB/s average over RGB (11 B/px) and RGBA (12 B/px) frames = {4096*4096*11.5/avg/8000*100:.1f} % of 8 TB/s")
     log = os.path.join(out, "writeout.log")
     if os.path.exists(log):
-        print(open(log).read().strip())
+        print("\n".join(l for l in open(log).read().splitlines() if l[:1].isdigit()))
 
 for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
     files = glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True)
