@@ -47,7 +47,8 @@ constexpr int SETUP_THREADS = 256;
 
 __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const DrawDesc* __restrict__ draws, int draw_idx,
                                                          TriRec* __restrict__ recs, uint32_t* __restrict__ cnt,
-                                                         uint2* __restrict__ tilebox, DevStats* __restrict__ stats) {
+                                                         uint2* __restrict__ tilebox, DevStats* __restrict__ stats,
+                                                         uint32_t* __restrict__ blk_sums, uint32_t blk_base) {
     __shared__ __attribute__((aligned(16))) double s_buf[SETUP_THREADS * 16];    // 32 KB: in [256][12], then out [256][16]
     __shared__ uint8_t s_keep[SETUP_THREADS];
     const DrawDesc& d = draws[draw_idx];
@@ -164,6 +165,16 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
             if (s_keep[t]) dst[k] = l4[t * 8 + (c ^ (t & 7))];
         }
     }
+    // pairs of this block of 256 triangles: k_expand derives every triangle's slice of the pair list from these sums
+    // (k_chunk_spine) and a block-level scan of `cnt`, so no scan pass ever walks the N-element arrays
+    {
+        uint32_t ws = ntiles;
+        for (int o = 32; o; o >>= 1) ws += __shfl_xor(ws, o);
+        __shared__ uint32_t s_ws[SETUP_THREADS / 64];
+        if ((tid & 63) == 0) s_ws[tid >> 6] = ws;
+        __syncthreads();
+        if (tid == 0) blk_sums[blk_base + blockIdx.x] = s_ws[0] + s_ws[1] + s_ws[2] + s_ws[3];
+    }
     // bbox stats (our_gl.cpp:138-141): one set of atomics per wave
     int wx0 = wave_min_i(bx0), wy0 = wave_min_i(by0), wx1 = wave_max_i(bx1), wy1 = wave_max_i(by1);
     // All waves hit the same four words, and same-address atomics serialise at ~11 ns each, so only
@@ -248,15 +259,49 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const uint32_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// expand: triangle i owns pairs [off[i], off[i]+cnt[i]) = its tiles in row-major order.
-// Triangles with many tiles are written by the whole wave.
+// pair offsets.  k_setup leaves one pair count per block of 256 triangles (blk_sums, blocks numbered across the
+// draws of the flush).  k_chunk_spine (one block) scans them in chunks of 16: chunk_off[c] = pairs before block 16c.
+// k_expand then finds its block's base (chunk offset + the <= 15 preceding block sums of its chunk) and scans the 256
+// counts of its own triangles in LDS.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_expand(uint32_t n, int tiles_x, const uint32_t* __restrict__ cnt,
-                                                const uint32_t* __restrict__ off, const uint2* __restrict__ tilebox,
+constexpr int EXPAND_CHUNK = 16;
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_chunk_spine(const uint32_t* __restrict__ blk_sums, uint32_t nblk,
+                                                               uint32_t* __restrict__ chunk_off,
+                                                               unsigned long long* __restrict__ total64) {
+    __shared__ uint32_t smem[4];
+    const uint32_t nchunks = (nblk + EXPAND_CHUNK - 1) / EXPAND_CHUNK;
+    unsigned long long running = 0;
+    for (uint32_t start = 0; start < nchunks; start += SCAN_THREADS) {
+        const uint32_t c = start + threadIdx.x;
+        uint32_t v = 0;
+        if (c < nchunks)
+            for (uint32_t q = c * EXPAND_CHUNK; q < min(nblk, (c + 1) * EXPAND_CHUNK); ++q) v += blk_sums[q];
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, smem, &tot);
+        if (c < nchunks) chunk_off[c] = (uint32_t)running + ex;
+        running += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total64 = running;
+}
+
+// expand: triangle i owns pairs [off, off + cnt[i]) = its tiles in row-major order; off is computed here.
+// Triangles with many tiles are written by the whole wave.  One launch per draw (same blocks as k_setup).
+__global__ __launch_bounds__(256) void k_expand(uint32_t first, uint32_t n, int tiles_x, const uint32_t* __restrict__ cnt,
+                                                const uint32_t* __restrict__ blk_sums, const uint32_t* __restrict__ chunk_off,
+                                                uint32_t blk_base, const uint2* __restrict__ tilebox,
                                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t c = 0, o = 0; uint2 tb = make_uint2(0, 0);
-    if (i < n) { c = cnt[i]; if (c) { o = off[i]; tb = tilebox[i]; } }
+    __shared__ uint32_t smem[4];
+    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = first + local;                          // index of the triangle within the flush
+    const uint32_t blk = blk_base + blockIdx.x;
+    uint32_t c = 0; uint2 tb = make_uint2(0, 0);
+    if (local < n) { c = cnt[i]; if (c) tb = tilebox[i]; }
+    uint32_t base = chunk_off[blk / EXPAND_CHUNK];
+    for (uint32_t q = blk - blk % EXPAND_CHUNK; q < blk; ++q) base += blk_sums[q];      // wave-uniform loads
+    uint32_t tot;
+    const uint32_t o = base + block_excl_scan(c, smem, &tot);
     constexpr uint32_t SMALL = 8;
     if (c && c <= SMALL) {
         uint32_t tx0 = tb.x & 0xffff, ty0 = tb.x >> 16, tx1 = tb.y & 0xffff;
@@ -410,10 +455,17 @@ __global__ __launch_bounds__(256) void k_bounds(const uint32_t* __restrict__ key
 // ---- launchers ----------------------------------------------------------------------------------
 namespace trgl {
 
+uint32_t setup_num_blocks(uint32_t n) { return (n + SETUP_THREADS - 1) / SETUP_THREADS; }
+
 void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc* draws_dev, int draw_idx, uint32_t n,
-                  TriRec* recs, uint32_t* cnt, uint2* tilebox, DevStats* stats) {
+                  TriRec* recs, uint32_t* cnt, uint2* tilebox, DevStats* stats, uint32_t* blk_sums, uint32_t blk_base) {
     if (!n) return;
-    hipLaunchKernelGGL(k_setup, dim3((n + 255) / 256), dim3(256), 0, s, fp, draws_dev, draw_idx, recs, cnt, tilebox, stats);
+    hipLaunchKernelGGL(k_setup, dim3(setup_num_blocks(n)), dim3(SETUP_THREADS), 0, s, fp, draws_dev, draw_idx, recs, cnt, tilebox,
+                       stats, blk_sums, blk_base);
+}
+
+void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, uint32_t* chunk_off, unsigned long long* total64) {
+    hipLaunchKernelGGL(k_chunk_spine, dim3(1), dim3(SCAN_THREADS), 0, s, blk_sums, nblk, chunk_off, total64);
 }
 
 uint32_t scan_num_blocks(uint64_t n) { return (uint32_t)((n + SCAN_ELEMS - 1) / SCAN_ELEMS); }
@@ -428,10 +480,11 @@ void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uin
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, block_sums, out);
 }
 
-void launch_expand(hipStream_t s, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* off,
-                   const uint2* tilebox, uint32_t* keys, uint32_t* vals) {
+void launch_expand(hipStream_t s, uint32_t first, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* blk_sums,
+                   const uint32_t* chunk_off, uint32_t blk_base, const uint2* tilebox, uint32_t* keys, uint32_t* vals) {
     if (!n) return;
-    hipLaunchKernelGGL(k_expand, dim3((n + 255) / 256), dim3(256), 0, s, n, tiles_x, cnt, off, tilebox, keys, vals);
+    hipLaunchKernelGGL(k_expand, dim3(setup_num_blocks(n)), dim3(SETUP_THREADS), 0, s, first, n, tiles_x, cnt, blk_sums, chunk_off,
+                       blk_base, tilebox, keys, vals);
 }
 
 uint32_t radix_num_workers(uint32_t P) { return (P + RADIX_CHUNK - 1) / RADIX_CHUNK; }   // = blocks of a pass

@@ -5,15 +5,18 @@
 
 namespace trgl {
 
+uint32_t setup_num_blocks(uint32_t n);      // blocks of 256 triangles of one draw (k_setup and k_expand use the same)
 void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc* draws_dev, int draw_idx, uint32_t n,
-                  TriRec* recs, uint32_t* cnt, uint2* tilebox, DevStats* stats);
+                  TriRec* recs, uint32_t* cnt, uint2* tilebox, DevStats* stats, uint32_t* blk_sums, uint32_t blk_base);
+// chunk_off[c] = pairs before setup block 16c; *total64 = all pairs of the flush
+void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, uint32_t* chunk_off, unsigned long long* total64);
 
 uint32_t scan_num_blocks(uint64_t n);
 void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* block_sums,
                            unsigned long long* total64);
 
-void launch_expand(hipStream_t s, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* off,
-                   const uint2* tilebox, uint32_t* keys, uint32_t* vals);
+void launch_expand(hipStream_t s, uint32_t first, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* blk_sums,
+                   const uint32_t* chunk_off, uint32_t blk_base, const uint2* tilebox, uint32_t* keys, uint32_t* vals);
 
 uint32_t radix_num_workers(uint32_t P);
 void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,

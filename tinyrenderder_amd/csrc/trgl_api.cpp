@@ -28,6 +28,7 @@ struct StageChunk { char* base; size_t cap, used; };
 
 struct trgl_ctx {
     int device = 0;
+    int num_cus = 256;          // multiProcessorCount of the device
     int W = 0, H = 0, bpp = 0, tiles_x = 0, tiles_y = 0;
     hipStream_t stream = nullptr;       // the stream in use
     hipStream_t own_stream = nullptr;   // created with the context
@@ -47,7 +48,9 @@ struct trgl_ctx {
     std::vector<StageChunk> stage;
     int stage_hold = 0;                 // >0 while a draw call has staged data that no DrawDesc references yet
 
-    TriRec* recs = nullptr; uint32_t* cnt = nullptr; uint32_t* off = nullptr; uint2* tilebox = nullptr;
+    TriRec* recs = nullptr; uint32_t* cnt = nullptr; uint2* tilebox = nullptr;
+    uint32_t* blk_sums = nullptr; size_t cap_blk = 0;       // pairs per setup block of 256 triangles
+    uint32_t* chunk_off = nullptr; size_t cap_chunk = 0;    // pairs before every 16th setup block
     size_t cap_tris = 0;
     uint32_t* keys[2] = { nullptr, nullptr }; uint32_t* vals[2] = { nullptr, nullptr };
     size_t cap_pairs = 0;
@@ -140,6 +143,7 @@ int trgl_create(int device, int width, int height, int bpp, trgl_ctx** out) {
     c->tiles_x = (width + TRGL_TILE - 1) / TRGL_TILE;
     c->tiles_y = (height + TRGL_TILE - 1) / TRGL_TILE;
     c->strip_y0 = 0; c->strip_y1 = height;
+    { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) c->num_cus = n; }
     std::memset(c->tex_host, 0, sizeof(c->tex_host));
     size_t npx = (size_t)width * height, ntiles = (size_t)c->tiles_x * c->tiles_y;
 #define CRE(expr) do { hipError_t e2 = (expr); if (e2 != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e2); trgl_destroy(c); return TRGL_E_HIP; } } while (0)
@@ -171,7 +175,7 @@ int trgl_destroy(trgl_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& s : c->stage) (void)hipFree(s.base);
     for (int i = 0; i < TRGL_MAX_TEXTURES; ++i) if (c->tex_host[i].data) (void)hipFree((void*)c->tex_host[i].data);
-    void* ptrs[] = { c->fb, c->zb, c->tex_dev, c->recs, c->cnt, c->off, c->tilebox, c->keys[0], c->keys[1], c->vals[0],
+    void* ptrs[] = { c->fb, c->zb, c->tex_dev, c->recs, c->cnt, c->blk_sums, c->chunk_off, c->tilebox, c->keys[0], c->keys[1], c->vals[0],
                      c->vals[1], c->hist, c->scan_tmp, c->tile_start, c->tile_end, c->draws_dev, c->stats_dev, c->items, c->n_items, c->item_stats };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->draws_pinned) (void)hipHostFree(c->draws_pinned);
@@ -424,17 +428,24 @@ int trgl_flush(trgl_ctx* c) {
             size_t ncap = N + N / 4 + 1024;
             if ((r = realloc_dev(c, (void**)&c->recs, ncap * sizeof(TriRec)))) return r;
             if ((r = realloc_dev(c, (void**)&c->cnt, ncap * 4))) return r;
-            if ((r = realloc_dev(c, (void**)&c->off, ncap * 4))) return r;
             if ((r = realloc_dev(c, (void**)&c->tilebox, ncap * sizeof(uint2)))) return r;
             c->cap_tris = ncap;
         }
-        if ((r = grow(c, c->scan_tmp, c->cap_scan, (size_t)scan_num_blocks(N) + 16))) return r;
         std::memcpy(c->draws_pinned, c->draws.data(), c->draws.size() * sizeof(DrawDesc));
         HIPCHK(c, hipMemcpyAsync(c->draws_dev, c->draws_pinned, c->draws.size() * sizeof(DrawDesc), hipMemcpyHostToDevice, s));
-        for (size_t i = 0; i < c->draws.size(); ++i)
-            launch_setup(s, fp, c->draws_dev, (int)i, c->draws[i].n, c->recs, c->cnt, c->tilebox, c->stats_dev);
+        uint32_t nblk = 0;
+        for (auto& d : c->draws) nblk += setup_num_blocks(d.n);
+        if ((r = grow(c, c->blk_sums, c->cap_blk, (size_t)nblk + 16))) return r;
+        if ((r = grow(c, c->chunk_off, c->cap_chunk, (size_t)nblk / 16 + 16))) return r;
+        {
+            uint32_t blk_base = 0;
+            for (size_t i = 0; i < c->draws.size(); ++i) {
+                launch_setup(s, fp, c->draws_dev, (int)i, c->draws[i].n, c->recs, c->cnt, c->tilebox, c->stats_dev, c->blk_sums, blk_base);
+                blk_base += setup_num_blocks(c->draws[i].n);
+            }
+        }
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
-        launch_exclusive_scan(s, c->cnt, c->off, N, c->scan_tmp, &c->stats_dev->pairs_total);
+        launch_chunk_spine(s, c->blk_sums, nblk, c->chunk_off, &c->stats_dev->pairs_total);
         HIPCHK(c, hipMemcpyAsync(&c->stats_pinned->pairs_total, &c->stats_dev->pairs_total, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         unsigned long long P64 = c->stats_pinned->pairs_total;
@@ -455,7 +466,13 @@ int trgl_flush(trgl_ctx* c) {
             }
             c->cap_pairs = ncap;
         }
-        launch_expand(s, (uint32_t)N, c->tiles_x, c->cnt, c->off, c->tilebox, c->keys[0], c->vals[0]);
+        {
+            uint32_t blk_base = 0;
+            for (auto& d : c->draws) {
+                launch_expand(s, d.first, d.n, c->tiles_x, c->cnt, c->blk_sums, c->chunk_off, blk_base, c->tilebox, c->keys[0], c->vals[0]);
+                blk_base += setup_num_blocks(d.n);
+            }
+        }
         int key_bits = 1; while ((size_t(1) << key_bits) < ntiles) ++key_bits;
         int passes = (key_bits + 7) / 8;
         int bits_per = (key_bits + passes - 1) / passes;
@@ -480,6 +497,13 @@ int trgl_flush(trgl_ctx* c) {
     const uint64_t strip_tiles = (uint64_t)(fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x;
     uint32_t split_len = 8;
     if (strip_tiles && 2 * (uint64_t)P / strip_tiles > split_len) split_len = (uint32_t)(2 * (uint64_t)P / strip_tiles);
+    // ... unless the strip has fewer tiles than the GPU has wave slots (a rank of a multi-GPU run, a small frame): then
+    // bands are what fills the machine, and the target is about one item per slot (16 waves per CU).
+    const uint64_t wave_slots = (uint64_t)c->num_cus * 16;
+    if (strip_tiles && strip_tiles < wave_slots) {
+        const uint64_t fill_len = 3 * (uint64_t)P / (2 * wave_slots);
+        if (fill_len < split_len) split_len = (uint32_t)(fill_len > 8 ? fill_len : 8);
+    }
     const uint32_t max_items = raster_max_items(fp, P, split_len);
     if ((r = grow(c, c->items, c->cap_items, (size_t)max_items + 64))) return r;
     if ((r = grow(c, c->item_stats, c->cap_item_stats, ((size_t)max_items + 64) * 4))) return r;
