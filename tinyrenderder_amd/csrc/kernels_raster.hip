@@ -249,6 +249,7 @@ struct TileState {
     double* zt;
     uint8_t* fb_lane;       // address of this lane's pixel of block 0 in the framebuffer (colours are written straight to it)
     int bpp; uint32_t row_bytes;   // framebuffer bytes per pixel / per row
+    uint32_t* id_lane; uint32_t row_px;   // PHONG / EYE flushes: this lane's pixel of block 0 in the visibility buffer, pixels per row
     uint32_t frags; double zmin, zmax; bool zero_locked;
 };
 
@@ -333,11 +334,17 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                     b2 = div_by_uz(ux, uz, ruz);
                 }
                 const double z = b0 * T.z0 + b1 * T.z1 + b2 * T.z2;           // :156-158
-                // :160 — on the well-scaled path b0..b2 and the NDC depths are finite and bounded, so z is finite
-                if ((WELL_SCALED || __builtin_isfinite(z)) && (z < zold)) {   // :165
-                    uint32_t color;
+                // :160 — checked on both paths: the NDC depths of a well-scaled triangle are finite but not bounded
+                if (__builtin_isfinite(z) && (z < zold)) {                    // :160, :165
+                    uint32_t color = 0;
+                    constexpr bool DEFERRED = KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE;
                     if (FLAT_ONLY) {
                         color = T.color;
+                    } else if (DEFERRED) {
+                        // visibility only: remember which triangle owns the pixel; k_shade runs the fragment shader once
+                        // per visible pixel when the list is done (the shaders have no side effects, so the image is the
+                        // same as shading every z-pass in order, and the counters do not depend on colours)
+                        S.id_lane[(size_t)(8 * cy) * S.row_px + (size_t)(8 * cx)] = bcast_u(tri_l, j);
                     } else {
                         const DrawDesc& d = draws[T.dl >> 24];
                         const int kind = KIND == KIND_ANY ? d.kind : KIND;
@@ -366,7 +373,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                     if (dropped) TRGL_DBG(7, 1);                              // must stay 0
 #endif
                     S.zt[li] = z;                                             // :191
-                    {                                                         // :192, tgaimage.cpp:32-39: straight to the framebuffer
+                    if (!DEFERRED) {                                          // :192, tgaimage.cpp:32-39: straight to the framebuffer
                         uint8_t* dst = S.fb_lane + ((size_t)(8 * cy) * S.row_bytes + (size_t)(8 * cx) * S.bpp);
                         if (S.bpp == 3) { dst[0] = (uint8_t)color; dst[1] = (uint8_t)(color >> 8); dst[2] = (uint8_t)(color >> 16); }
                         else if (S.bpp == 4) *reinterpret_cast<uint32_t*>(dst) = color;
@@ -451,7 +458,7 @@ __device__ __forceinline__ void tile_clear_color(const FrameParams& fp, int lane
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND <= TRGL_SHADER_GOURAUD ? 4 : 3, KIND <= TRGL_SHADER_GOURAUD ? 4 : 3))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND != KIND_ANY ? 4 : 3, KIND != KIND_ANY ? 4 : 3))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
                                                 const uint32_t* __restrict__ tile_start,
                                                 const uint32_t* __restrict__ tile_end,
@@ -506,11 +513,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND <= TRG
     // straight into the framebuffer (TGAImage::set, tgaimage.cpp:32-39).  With aligned blocks the same lane owns a
     // pixel every time, so successive writes to a pixel are same-thread, same-address stores and keep program order.
     // 8.6 KB of LDS per wave instead of 12.6 KB = 16 waves per CU instead of 12, and no colour tile in / out.
+    constexpr bool DEFERRED = KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE;
+    if (DEFERRED) {                                      // visibility buffer of the rows this item owns: no owner yet
+        for (int r2 = 0; r2 < TRGL_TILE; r2 += 2) {
+            const int x = px0 + (lane & 31), y = py0 + r2 + (lane >> 5);
+            if (x <= xa1 && y >= ya0 && y <= ya1) fp.idbuf[(size_t)x + (size_t)y * fp.W] = 0xffffffffu;
+        }
+    }
     if (fp.init_from_clear) {
         for (int k = lane; k < TRGL_TILE_PIX; k += 64) zt[k] = fp.clear_z;
         tile_clear_color(fp, lane, px0, py0, xa1, ya0, ya1);
-        // other lanes wrote these bytes: have the stores acknowledged before any fragment of this wave follows them
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         for (int r = 0; r < TRGL_TILE; r += 2) {
             int x = px0 + (lane & 31), y = py0 + r + (lane >> 5);
@@ -519,6 +531,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND <= TRG
             zt[lds_index(x, y)] = z;
         }
     }
+    // other lanes wrote the clear colour / empty owner of this lane's pixels: have those stores acknowledged before any
+    // fragment of this wave follows them
+    if (fp.init_from_clear || DEFERRED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     constexpr bool FLAT_ONLY = KIND == TRGL_SHADER_FLAT;
     // GOURAUD's 3 intensities + base colour ride along with the records (lane j of V); PHONG / EYE have 24 doubles of
@@ -534,6 +549,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND <= TRG
     S.lane = lane; S.px0 = px0; S.py0 = py0; S.xa1 = xa1; S.ya0 = ya0; S.ya1 = ya1; S.zt = zt;
     S.bpp = fp.bpp; S.row_bytes = (uint32_t)fp.W * (uint32_t)fp.bpp;
     S.fb_lane = fp.fb + ((size_t)(py0 + (lane >> 3)) * fp.W + (size_t)(px0 + (lane & 7))) * fp.bpp;
+    S.row_px = (uint32_t)fp.W;
+    S.id_lane = DEFERRED ? fp.idbuf + ((size_t)(py0 + (lane >> 3)) * fp.W + (size_t)(px0 + (lane & 7))) : nullptr;
     S.lxm = ((double)(lane & 7) + 0.5) - 0x1p51; S.lym = ((double)(lane >> 3) + 0.5) - 0x1p51;
     S.lrow = (lane >> 3) * 32 + (lane & 7); S.lsw = ((lane >> 3) & 3) << 3;
     S.frags = 0; S.zmin = __builtin_inf(); S.zmax = -__builtin_inf();
@@ -735,6 +752,79 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND <= TRG
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_shade<PHONG|EYE>: the fragment stage of a PHONG / EYE flush, once per visible pixel.
+// k_raster left, for every pixel whose depth it wrote in this flush, the record index of the LAST triangle that passed the
+// z-test there (fp.idbuf).  IShader::fragment has no side effects and always returns discard = false (main.cpp:92-170,
+// 220-261), so calling it for that triangle only gives the same framebuffer as calling it for every z-pass in order
+// (our_gl.cpp:187-192) - with 64 busy lanes per wave instead of the few pixels of one small triangle.  One wave per
+// work item of k_raster (so tiles this flush did not touch are not visited), 16 aligned 8x8 blocks each; the
+// barycentrics are recomputed per pixel with exactly the operations of the scan (same bits).
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void k_shade(FrameParams fp, const TriRec* __restrict__ recs, const DrawDesc* __restrict__ draws,
+                                                const DevTexture* __restrict__ tex, const uint32_t* __restrict__ tile_start,
+                                                const uint32_t* __restrict__ tile_end, const uint32_t* __restrict__ items,
+                                                const uint32_t* __restrict__ n_items) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t item_idx = blockIdx.x * TRGL_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (item_idx >= *n_items) return;
+    const uint32_t item = items[item_idx];
+    const int t = (int)(item & 0xffffffu);
+    if (tile_start[t] == tile_end[t]) return;            // no triangles: k_raster did not touch this tile's owners
+    const int band = (int)((item >> 24) & 0xf), band_log2 = (int)(item >> 28);
+    const int tile_y = t / fp.tiles_x, tile_x = t - tile_y * fp.tiles_x;
+    const int px0 = tile_x << TRGL_TILE_LOG2, py0 = tile_y << TRGL_TILE_LOG2;
+    const int band_rows = TRGL_TILE >> band_log2;
+    const int xa1 = min(px0 + TRGL_TILE - 1, fp.W - 1);
+    const int ya0 = max(py0 + band * band_rows, fp.strip_y0);
+    const int ya1 = min(min(py0 + (band + 1) * band_rows - 1, fp.H - 1), fp.strip_y1 - 1);
+    for (int k = 0; k < 16; ++k) {
+        const int x = px0 + 8 * (k & 3) + (lane & 7), y = py0 + 8 * (k >> 2) + (lane >> 3);
+        const bool mine = x <= xa1 && y >= ya0 && y <= ya1;
+        const size_t idx = (size_t)x + (size_t)y * fp.W;
+        const uint32_t id = mine ? fp.idbuf[idx] : 0xffffffffu;
+        if (id == 0xffffffffu) continue;
+        const TriRec& r = recs[id];
+        // barycentric(), our_gl.cpp:77-86, as in raster_triangle
+        const double pxc = (double)x + 0.5, pyc = (double)y + 0.5;
+        const double s0z = r.ax - pxc, s1z = r.ay - pyc;
+        const double ux = r.s0y * s1z - s0z * r.s1y;
+        const double uy = s0z * r.s1x - r.s0x * s1z;
+        const double us = ux + uy;
+        double b0, b1, b2;
+        if (r.ruz != 0.0) {
+            b0 = 1.0 - div_by_uz(us, r.uz, r.ruz); b1 = div_by_uz(uy, r.uz, r.ruz); b2 = div_by_uz(ux, r.uz, r.ruz);
+        } else {
+            b0 = 1.0 - us / r.uz; b1 = uy / r.uz; b2 = ux / r.uz;
+        }
+        double pc[3];
+        const double denom = b0 * r.iw0 + b1 * r.iw1 + b2 * r.iw2;                        // our_gl.cpp:172-174
+        if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }                  // :177-185
+        else { pc[0] = (b0 * r.iw0) / denom; pc[1] = (b1 * r.iw1) / denom; pc[2] = (b2 * r.iw2) / denom; }
+        // the draw (uniforms, varyings array) is wave-uniform in all but exotic flushes: serve one draw at a time
+        const uint32_t dl = r.dl;
+        uint32_t color = 0;
+        unsigned long long todo = __ballot(true);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            const uint32_t di = (uint32_t)__builtin_amdgcn_readlane((int)(dl >> 24), src);
+            const bool here = (dl >> 24) == di;
+            todo &= ~__ballot(here);
+            if (here) {
+                const DrawDesc& d = draws[di];
+                const double* vary = d.vary + (size_t)(dl & 0xffffffu) * 24;
+                color = KIND == TRGL_SHADER_PHONG ? frag_phong(d.u, tex, vary, pc).bgra : frag_eye(d.u, tex, vary, pc).bgra;
+            }
+        }
+        uint8_t* dst = fp.fb + idx * fp.bpp;                                               // TGAImage::set, tgaimage.cpp:32-39
+        if (fp.bpp == 3) { dst[0] = (uint8_t)color; dst[1] = (uint8_t)(color >> 8); dst[2] = (uint8_t)(color >> 16); }
+        else if (fp.bpp == 4) *reinterpret_cast<uint32_t*>(dst) = color;
+        else for (int i = 0; i < fp.bpp; ++i) dst[i] = (uint8_t)(color >> (8 * i));
+    }
+}
+
 // ---- self-test of the two exactness shortcuts, against the hardware's IEEE division ------------------
 __device__ __forceinline__ unsigned long long sm64(unsigned long long& st) {
     unsigned long long z = (st += 0x9E3779B97F4A7C15ull);
@@ -889,6 +979,8 @@ void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER
     }
 #undef TRGL_LAUNCH_RASTER
     if (ev_after) (void)hipEventRecord(ev_after, s);
+    if (kind == TRGL_SHADER_PHONG) hipLaunchKernelGGL(k_shade<TRGL_SHADER_PHONG>, grid, dim3(256), 0, s, fp, recs, draws, tex, tile_start, tile_end, items, n_items);
+    if (kind == TRGL_SHADER_EYE) hipLaunchKernelGGL(k_shade<TRGL_SHADER_EYE>, grid, dim3(256), 0, s, fp, recs, draws, tex, tile_start, tile_end, items, n_items);
     hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(1024), 0, s, stats, n_items, item_stats);
 }
 

@@ -49,6 +49,7 @@ struct trgl_ctx {
     int stage_hold = 0;                 // >0 while a draw call has staged data that no DrawDesc references yet
 
     TriRec* recs = nullptr; uint32_t* cnt = nullptr; uint2* tilebox = nullptr;
+    uint32_t* idbuf = nullptr; size_t cap_idbuf = 0;        // visibility buffer of PHONG / EYE flushes, [H][W]
     uint32_t* blk_sums = nullptr; size_t cap_blk = 0;       // pairs per setup block of 256 triangles
     uint32_t* chunk_off = nullptr; size_t cap_chunk = 0;    // pairs before every 16th setup block
     size_t cap_tris = 0;
@@ -175,7 +176,7 @@ int trgl_destroy(trgl_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& s : c->stage) (void)hipFree(s.base);
     for (int i = 0; i < TRGL_MAX_TEXTURES; ++i) if (c->tex_host[i].data) (void)hipFree((void*)c->tex_host[i].data);
-    void* ptrs[] = { c->fb, c->zb, c->tex_dev, c->recs, c->cnt, c->blk_sums, c->chunk_off, c->tilebox, c->keys[0], c->keys[1], c->vals[0],
+    void* ptrs[] = { c->fb, c->zb, c->tex_dev, c->recs, c->cnt, c->idbuf, c->blk_sums, c->chunk_off, c->tilebox, c->keys[0], c->keys[1], c->vals[0],
                      c->vals[1], c->hist, c->scan_tmp, c->tile_start, c->tile_end, c->draws_dev, c->stats_dev, c->items, c->n_items, c->item_stats };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->draws_pinned) (void)hipHostFree(c->draws_pinned);
@@ -419,6 +420,10 @@ int trgl_flush(trgl_ctx* c) {
 
     int flush_kind = c->draws.empty() ? TRGL_SHADER_FLAT : c->draws[0].kind;     // one kind for the whole flush, or -1
     for (auto& d : c->draws) if (d.kind != flush_kind) flush_kind = -1;
+    if (flush_kind == TRGL_SHADER_PHONG || flush_kind == TRGL_SHADER_EYE) {       // shaded once per visible pixel (k_shade)
+        if ((r = grow(c, c->idbuf, c->cap_idbuf, (size_t)c->W * c->H))) return r;
+        fp.idbuf = c->idbuf;
+    }
 
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
     uint32_t P = 0;
