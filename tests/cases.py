@@ -118,6 +118,19 @@ def zclear_finite_128():
     return _case(128, 128, [(FLAT, None, clip, None, col)], bpp=4, clear=(7, 8, 9, 10), zclear=0.25)
 
 
+def huge_depths_128():
+    """NDC depths up to 1.7e308 on vertices 1 and 2 (vertex 0 stays inside [-1, 1], so our_gl.cpp:103-106 keeps the
+    triangle): the interpolated depth (our_gl.cpp:156-158) overflows to +-inf or lands on huge finite values, and
+    our_gl.cpp:160 drops the non-finite ones.  The screen coordinates stay ordinary ('well scaled')."""
+    clip, col = scenes.random_triangles(600, 128, 128, seed=23, rmin=4, rmax=48)
+    clip = clip.copy()
+    clip[0::5, 6] = 1.7e308;   clip[0::5, 10] = 1.7e308       # sum overflows to +inf
+    clip[1::5, 6] = -1.7e308;  clip[1::5, 10] = -1.7e308      # ... to -inf (would win every z-test if it were written)
+    clip[2::5, 6] = 1.7e308;   clip[2::5, 10] = -1.7e308      # huge cancelling terms: finite or not depending on the pixel
+    clip[3::5, 6] = -1e300                                     # huge but finite: wins where covered
+    return _case(128, 128, [(FLAT, None, clip, None, col)])
+
+
 def empty_scene_64():
     return _case(64, 64, [])
 
@@ -125,7 +138,7 @@ def empty_scene_64():
 CASES = {f.__name__: f for f in (
     flat_small_64, flat_800, flat_persp_512, flat_big_tris_512, edge_256, grid_256, grid_fine_128, gouraud_256_rgba,
     phong_512, phong_nomaps_256, eye_256, multi_draw_320x200, odd_dims_101x67, gray_bpp1_96x64,
-    viewport_offset_256x160, zclear_finite_128, empty_scene_64)}
+    viewport_offset_256x160, zclear_finite_128, huge_depths_128, empty_scene_64)}
 
 # cases whose full buffers are stored in tests/golden/ (small enough to commit)
 FULL_BUFFER_CASES = ("flat_small_64", "odd_dims_101x67", "gray_bpp1_96x64")

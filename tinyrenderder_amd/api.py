@@ -323,8 +323,8 @@ class Context:
     def stats_line(self) -> str:
         s = Stats()
         self._chk(self.L.trgl_get_stats(self.h, C.byref(s)))
-        buf = C.create_string_buffer(256)
-        self._chk(self.L.trgl_format_stats(C.byref(s), buf, 256))
+        buf = C.create_string_buffer(1024)
+        self._chk(self.L.trgl_format_stats(C.byref(s), buf, 1024))
         return buf.value.decode().strip()
 
     def reset_stats(self):

@@ -599,7 +599,7 @@ int trgl_reset_stats(trgl_ctx* c) {
 
 int trgl_format_stats(const trgl_stats* s, char* buf, size_t buflen) {   // our_gl.cpp:205-209
     if (!s || !buf) return TRGL_E_INVALID;
-    char lo[64], hi[64];
+    char lo[400], hi[400];      // "%f" of a double needs up to 317 characters
     if (std::isfinite(s->min_z)) std::snprintf(lo, sizeof lo, "%f", s->min_z); else std::snprintf(lo, sizeof lo, "inf");
     if (std::isfinite(s->max_z)) std::snprintf(hi, sizeof hi, "%f", s->max_z); else std::snprintf(hi, sizeof hi, "-inf");
     int n = std::snprintf(buf, buflen, "DEBUG: triangles=%llu fragments_drawn=%llu bbox=[%d,%d] - [%d,%d] z-range=[%s,%s]\n",

@@ -216,7 +216,7 @@ inline void print_render_stats() {                                              
     trgl_stats st{};
     if (s.ctx) { trgl_shim::submit_batch(); TRGL_SHIM_CHK(trgl_get_stats(s.ctx, &st)); }
     else { st.min_x = st.min_y = INT32_MAX; st.max_x = st.max_y = INT32_MIN; st.min_z = std::numeric_limits<double>::infinity(); st.max_z = -st.min_z; }
-    char line[256];
+    char line[1024];
     trgl_format_stats(&st, line, sizeof line);
     std::fputs(line, stderr);
 }
