@@ -194,6 +194,19 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": raster_ms},
         }
+        # the two streaming phases next to the raster kernel, as bytes moved per second (HIP-event phase times):
+        # k_setup reads 96 B of vertices + 4 B of colour and writes a 128-B record + 12 B per triangle; binning moves
+        # 52 B per pair (expand 8, two histogram reads 8, two scatter passes 32, bounds 4) + 12 B per triangle
+        setup_ms = phase_ms[PHASE_SETUP] / max(nfl, 1)
+        bin_ms = phase_ms[PHASE_BIN] / max(nfl, 1)
+        if kind == FLAT and setup_ms > 0 and bin_ms > 0:
+            setup_bytes = N * (96 + 4 + 12) + (N / world) * 128
+            bin_bytes = info["pairs"] * 52 + N * 12
+            out["streaming_phases"] = {
+                "k_setup": {"bytes": setup_bytes, "ms": setup_ms, "achieved": setup_bytes / (setup_ms * 1e-3) / 1e9,
+                            "unit": "GB/s", "frac": setup_bytes / (setup_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "binning": {"bytes": bin_bytes, "ms": bin_ms, "achieved": bin_bytes / (bin_ms * 1e-3) / 1e9,
+                            "unit": "GB/s", "frac": bin_bytes / (bin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         if writeout:
             out["writeout"] = writeout
         if world == 1 and args.cpu_sample > 0 and args.workload == "c4":
