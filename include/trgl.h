@@ -216,13 +216,21 @@ void trgl_ssao_defaults(trgl_ssao_params* p);
  * computed too (it is, internally).  params NULL = the reference's constants.  Implies flush + sync. */
 int trgl_postprocess(trgl_ctx* ctx, const trgl_ssao_params* params, uint8_t* zbuffer_image, uint8_t* ao_map, uint8_t* final_image);
 
-/* ---- TGA writer (host only) ------------------------------------------------ */
+/* ---- TGA writer and reader (host only) ------------------------------------- */
 
 /* Replaces: TGAImage::write_tga_file(name, vflip, rle) (tgaimage.cpp:161-242): produces exactly the bytes the
  * reference writes — 18-byte header (tgaimage.h:10-25), no footer, its RLE packetisation.  `out` needs
  * trgl_tga_max_size(w,h,bpp) bytes; *out_len receives the file length.  Needs no GPU and no context. */
 size_t trgl_tga_max_size(int w, int h, int bpp);
 int trgl_tga_encode(const uint8_t* pixels, int w, int h, int bpp, int vflip, int rle, uint8_t* out, size_t* out_len);
+
+/* Replaces: TGAImage::read_tga_file + load_rle_data (tgaimage.cpp:76-160) on a .tga file image held in memory - the maps
+ * sampled at model.cpp:415-459 reach the path through it.  trgl_tga_info parses the 18-byte header; trgl_tga_decode
+ * fills width*height*bpp bytes in TGAImage::buffer() order (after the origin flips of tgaimage.cpp:118-119), with the
+ * reference's treatment of truncated files (missing raw bytes stay 0, a cut RLE stream repeats the last colour).
+ * Both return TRGL_E_INVALID where the reference returns false.  Needs no GPU and no context. */
+int trgl_tga_info(const uint8_t* file, size_t size, int* width, int* height, int* bpp);
+int trgl_tga_decode(const uint8_t* file, size_t size, uint8_t* pixels);
 
 /* ---- OBJ reader (host only) -------------------------------------------------- */
 

@@ -87,6 +87,8 @@ def lib():
         L.orc_interp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_tga_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_tga_encode.restype = C.c_uint64
+        L.orc_tga_decode.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_uint64]
+        L.orc_tga_decode.restype = C.c_int
         L.orc_vertex_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.orc_zbuffer_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_ssao.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -239,6 +241,31 @@ def run_reference_tga(img: np.ndarray, vflip=True, rle=True) -> bytes:
             f.write(img.tobytes())
         subprocess.run([REF_HARNESS, "tga", ip, op], check=True)
         return open(op, "rb").read()
+
+
+def tga_decode(file_bytes: bytes):
+    """TGAImage::read_tga_file on a file image, via the C restatement: [h,w,bpp] uint8, or None where it returns false."""
+    buf = np.frombuffer(file_bytes, np.uint8)
+    w, h, bpp = C.c_int(), C.c_int(), C.c_int()
+    cap = 16 if len(buf) < 18 else (int(buf[12]) | (int(buf[13]) << 8)) * (int(buf[14]) | (int(buf[15]) << 8)) * 4 + 16
+    out = np.empty(cap, np.uint8)
+    ok = lib().orc_tga_decode(buf.ctypes.data if len(buf) else None, len(buf), C.byref(w), C.byref(h), C.byref(bpp), out.ctypes.data, out.size)
+    if not ok:
+        return None
+    return out[:w.value * h.value * bpp.value].reshape(h.value, w.value, bpp.value).copy()
+
+
+def run_reference_tga_read(file_bytes: bytes):
+    """What the reference's own TGAImage::read_tga_file makes of the file (build container only): array or None."""
+    with tempfile.TemporaryDirectory() as d:
+        ip, op = os.path.join(d, "in.tga"), os.path.join(d, "out.bin")
+        open(ip, "wb").write(file_bytes)
+        subprocess.run([REF_HARNESS, "tgaread", ip, op], check=True, stderr=subprocess.DEVNULL)
+        raw = open(op, "rb").read()
+    ok, w, h, bpp = struct.unpack("<4i", raw[:16])
+    if not ok:
+        return None
+    return np.frombuffer(raw[16:], np.uint8).reshape(h, w, bpp).copy()
 
 
 def vertex_stage(model_view, projection, vertices, indices):

@@ -191,12 +191,25 @@ int run_tga(const char* in_path, const char* out_path) {
     return img.write_tga_file(out_path, vflip != 0, rle != 0) ? 0 : 3;      // tgaimage.cpp:161-191
 }
 
+// tgaread: input = a .tga file; output = int32 ok, w, h, bpp + (if ok) the TGAImage buffer after TGAImage::read_tga_file.
+int run_tgaread(const char* in_path, const char* out_path) {
+    TGAImage img;
+    const bool ok = img.read_tga_file(in_path);                                   // tgaimage.cpp:76-126
+    std::ofstream out(out_path, std::ios::binary);
+    int32_t hd[4] = { ok ? 1 : 0, img.width(), img.height(), 0 };
+    if (ok) hd[3] = img.get(0, 0).bytespp;                                         // TGAColor(p, bpp), tgaimage.h:47-51
+    out.write((const char*)hd, sizeof hd);
+    if (ok) out.write((const char*)img.buffer(), (std::streamsize)hd[1] * hd[2] * hd[3]);
+    return out ? 0 : 3;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
     if (argc == 4 && std::strcmp(argv[1], "scene") == 0) return run_scene(argv[2], argv[3]);
     if (argc == 4 && std::strcmp(argv[1], "vecops") == 0) return run_vecops(argv[2], argv[3]);
     if (argc == 4 && std::strcmp(argv[1], "tga") == 0) return run_tga(argv[2], argv[3]);
-    std::fprintf(stderr, "usage: ref_harness scene|vecops|tga <in> <out>\n");
+    if (argc == 4 && std::strcmp(argv[1], "tgaread") == 0) return run_tgaread(argv[2], argv[3]);
+    std::fprintf(stderr, "usage: ref_harness scene|vecops|tga|tgaread <in> <out>\n");
     return 1;
 }

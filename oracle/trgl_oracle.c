@@ -512,3 +512,73 @@ void orc_composite(const uint8_t* fb, const uint8_t* ao, int w, int h, uint8_t* 
         for (int c = 0; c < 3; ++c) out[3 * i + c] = (unsigned char)dmin(255.0, (double)fb[3 * i + c] * ao_factor);
     }
 }
+
+/* TGAImage::read_tga_file + load_rle_data — tgaimage.cpp:76-160, on a file image in memory.  std::ifstream semantics are
+ * spelled out: a short read delivers what is there and fails the stream; afterwards every read is a no-op.
+ * Returns 1 where the reference returns true (w, h, bpp and w*h*bpp pixel bytes written), else 0. */
+typedef struct { const uint8_t* p; size_t n, pos; int good; } orc_stream;
+static void orc_read(orc_stream* s, uint8_t* dst, size_t k) {
+    if (!s->good) return;
+    size_t avail = s->pos < s->n ? s->n - s->pos : 0, m = k < avail ? k : avail;
+    if (m) memcpy(dst, s->p + s->pos, m);
+    s->pos += m;
+    if (m < k) s->good = 0;
+}
+int orc_tga_decode(const uint8_t* file, uint64_t size, int* pw, int* ph, int* pbpp, uint8_t* data, uint64_t cap) {
+    orc_stream in = { file, (size_t)size, 0, 1 };
+    uint8_t hd[18] = { 0 };
+    orc_read(&in, hd, 18);                                              /* :85 */
+    if (!in.good) return 0;                                              /* :86-90 */
+    int w = hd[12] | (hd[13] << 8), h = hd[14] | (hd[15] << 8), bpp = hd[16] >> 3;   /* :92-94 */
+    *pw = w; *ph = h; *pbpp = bpp;
+    if (w <= 0 || h <= 0 || (bpp != 1 && bpp != 3 && bpp != 4)) return 0;            /* :96-99 */
+    if ((uint64_t)w * h * bpp > cap) return 0;
+    memset(data, 0, (size_t)w * h * bpp);                                /* :101 data.resize() */
+    in.pos += hd[0];                                                     /* :103 seekg(idlength, cur) */
+    if (hd[2] == 2 || hd[2] == 3) {                                      /* :105-108 */
+        orc_read(&in, data, (size_t)w * h * bpp);
+    } else if (hd[2] == 10 || hd[2] == 11) {                             /* :109-112, load_rle_data :128-160 */
+        int pixelcount = w * h, currentpixel = 0;
+        uint8_t c[4] = { 0, 0, 0, 255 };                                 /* TGAColor c; tgaimage.h:33 */
+        while (currentpixel < pixelcount) {
+            uint8_t chunkheader = 0;
+            orc_read(&in, &chunkheader, 1);
+            if (chunkheader < 128) {
+                int count = chunkheader + 1;
+                for (int i = 0; i < count; i++) {
+                    orc_read(&in, c, (size_t)bpp);
+                    if (currentpixel >= pixelcount) return 0;            /* the reference writes out of bounds here, then fails (:145) */
+                    for (int t = 0; t < bpp; t++) data[currentpixel * bpp + t] = c[t];
+                    currentpixel++;
+                }
+            } else {
+                int count = chunkheader - 127;
+                orc_read(&in, c, (size_t)bpp);
+                for (int i = 0; i < count; i++) {
+                    if (currentpixel >= pixelcount) return 0;            /* :155 */
+                    for (int t = 0; t < bpp; t++) data[currentpixel * bpp + t] = c[t];
+                    currentpixel++;
+                }
+            }
+        }
+    } else return 0;                                                     /* :113-116 */
+    int bytes_per_line = w * bpp;
+    if (!(hd[17] & 0x20)) {                                              /* :118 flip_vertically, :59-71 */
+        for (int y = 0; y < h / 2; y++)
+            for (int k = 0; k < bytes_per_line; k++) {
+                uint8_t t = data[y * bytes_per_line + k];
+                data[y * bytes_per_line + k] = data[(h - 1 - y) * bytes_per_line + k];
+                data[(h - 1 - y) * bytes_per_line + k] = t;
+            }
+    }
+    if (hd[17] & 0x10) {                                                 /* :119 flip_horizontally, :42-57 */
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w / 2; x++)
+                for (int i = 0; i < bpp; i++) {
+                    uint8_t t = data[y * bytes_per_line + x * bpp + i];
+                    data[y * bytes_per_line + x * bpp + i] = data[y * bytes_per_line + (w - 1 - x) * bpp + i];
+                    data[y * bytes_per_line + (w - 1 - x) * bpp + i] = t;
+                }
+    }
+    return 1;
+}

@@ -62,6 +62,8 @@ void orc_interp(const double* v0, const double* v1, const double* v2, const doub
 /* The bytes TGAImage::write_tga_file(name, vflip, rle) writes (tgaimage.cpp:161-242, header tgaimage.h:10-25).
  * out must hold 18 + w*h*bpp + w*h bytes (worst case); returns the length. */
 uint64_t orc_tga_encode(const uint8_t* data, int w, int h, int bpp, int vflip, int rle, uint8_t* out);
+/* TGAImage::read_tga_file + load_rle_data (tgaimage.cpp:76-160) on a file image in memory; 1 = the reference returns true. */
+int orc_tga_decode(const uint8_t* file, uint64_t size, int* w, int* h, int* bpp, uint8_t* data, uint64_t cap);
 
 /* ---- SURVEY.md §8(f) next rows, restated from main.cpp (unbuildable here: "parity unpinned" vs a compiled main.cpp) ---- */
 

@@ -47,3 +47,49 @@ def test_tga_random_images_against_reference_binary():
     for bpp in (1, 3, 4):
         img = (rng.integers(0, 3, size=(37, 53, bpp)) * 120).astype(np.uint8)     # few colours: lots of runs
         assert api.tga_encode(img) == orc.run_reference_tga(img)
+
+
+# ---- reader (tgaimage.cpp:76-160): fixtures decoded by the reference's own read_tga_file ------------------------------
+READ_GOLD = json.load(open(os.path.join(HERE, "golden", "tga_read_golden.json")))
+
+
+def _fixture(name):
+    return open(os.path.join(HERE, "golden", "tga_read", name + ".tga"), "rb").read()
+
+
+@pytest.mark.parametrize("name", sorted(READ_GOLD))
+def test_tga_reader_matches_reference_reader(name):
+    """Product decoder (C ABI) and C restatement vs what TGAImage::read_tga_file made of the same file: origins, id field,
+    truncated raw / RLE data (not errors in the reference), overrunning packets and unsupported headers (errors)."""
+    data, gold = _fixture(name), READ_GOLD[name]
+    restated = orc.tga_decode(data)
+    if not gold["ok"]:
+        assert restated is None
+        with pytest.raises(api.TrglError):
+            api.tga_decode(data)
+        return
+    got = api.tga_decode(data)
+    assert list(got.shape) == gold["shape"] and hashlib.sha256(got.tobytes()).hexdigest() == gold["sha256"]
+    assert np.array_equal(got, restated)
+
+
+def test_tga_write_read_round_trip_is_the_references():
+    """write_tga_file(vflip=true) marks the file bottom-origin without reordering rows, and read_tga_file flips such files:
+    a round trip through the reference turns the image upside down unless vflip=false.  Same here."""
+    img = (np.arange(6 * 5 * 3) % 251).astype(np.uint8).reshape(5, 6, 3)
+    for rle in (False, True):
+        assert np.array_equal(api.tga_decode(api.tga_encode(img, vflip=False, rle=rle)), img)
+        assert np.array_equal(api.tga_decode(api.tga_encode(img, vflip=True, rle=rle)), img[::-1])
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not orc.ref_available(), reason="oracle/_ref not built (reference tree absent)")
+def test_tga_reader_random_files_against_reference_binary():
+    rng = np.random.default_rng(9)
+    for bpp in (1, 3, 4):
+        img = (rng.integers(0, 3, size=(23, 31, bpp)) * 120).astype(np.uint8)
+        for vflip in (False, True):
+            f = bytearray(api.tga_encode(img, vflip, True))
+            for cut in (len(f), len(f) - 7, 60):
+                ref = orc.run_reference_tga_read(bytes(f[:cut]))
+                assert np.array_equal(api.tga_decode(bytes(f[:cut])), ref) and np.array_equal(orc.tga_decode(bytes(f[:cut])), ref)

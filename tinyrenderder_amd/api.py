@@ -28,7 +28,7 @@ SYMBOLS = [
     "trgl_write_framebuffer", "trgl_read_zbuffer", "trgl_write_zbuffer", "trgl_get_stats", "trgl_reset_stats",
     "trgl_format_stats", "trgl_framebuffer_device_ptr", "trgl_zbuffer_device_ptr", "trgl_stream", "trgl_set_stream",
     "trgl_set_profiling", "trgl_get_phase_ms", "trgl_reset_phase_ms", "trgl_get_last_flush_info",
-    "trgl_selftest_division", "trgl_tga_max_size", "trgl_tga_encode", "trgl_draw_indexed", "trgl_ssao_defaults",
+    "trgl_selftest_division", "trgl_tga_max_size", "trgl_tga_encode", "trgl_tga_info", "trgl_tga_decode", "trgl_draw_indexed", "trgl_ssao_defaults",
     "trgl_postprocess", "trgl_obj_load", "trgl_obj_free",
 ]
 
@@ -134,6 +134,8 @@ def load_library(path: str = LIB_PATH):
     L.trgl_tga_max_size.argtypes = [C.c_int, C.c_int, C.c_int]
     L.trgl_tga_max_size.restype = C.c_size_t
     L.trgl_tga_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_size_t)]
+    L.trgl_tga_info.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.trgl_tga_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     for name in SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int and name not in ("trgl_last_error",):
@@ -166,6 +168,22 @@ def tga_encode(img, vflip: bool = True, rle: bool = True) -> bytes:
     if rc != 0:
         raise TrglError(f"trgl_tga_encode failed ({rc})")
     return out[:n.value].tobytes()
+
+
+def tga_decode(file_bytes: bytes):
+    """TGAImage::read_tga_file on a .tga file image: [h,w,bpp] uint8 in TGAImage::buffer() order (host only).
+    Raises TrglError where the reference returns false."""
+    L = load_library()
+    buf = np.frombuffer(file_bytes, np.uint8)
+    w, h, bpp = C.c_int(), C.c_int(), C.c_int()
+    rc = L.trgl_tga_info(buf.ctypes.data if len(buf) else None, len(buf), C.byref(w), C.byref(h), C.byref(bpp))
+    if rc != 0:
+        raise TrglError(f"trgl_tga_info: not a TGA file the reference reads ({rc})")
+    out = np.empty((h.value, w.value, bpp.value), np.uint8)
+    rc = L.trgl_tga_decode(buf.ctypes.data, len(buf), out.ctypes.data)
+    if rc != 0:
+        raise TrglError(f"trgl_tga_decode failed ({rc})")
+    return out
 
 
 def load_obj(path: str):

@@ -641,6 +641,23 @@ int trgl_tga_encode(const uint8_t* pixels, int w, int h, int bpp, int vflip, int
     return TRGL_OK;
 }
 
+int trgl_tga_info(const uint8_t* file, size_t size, int* width, int* height, int* bpp) {
+    if (!file || !width || !height || !bpp || size < 18) return TRGL_E_INVALID;            // tgaimage.cpp:85-90
+    const int w = file[12] | (file[13] << 8), h = file[14] | (file[15] << 8), b = file[16] >> 3;
+    if (w <= 0 || h <= 0 || (b != 1 && b != 3 && b != 4)) return TRGL_E_INVALID;           // :96-99
+    if (!(file[2] == 2 || file[2] == 3 || file[2] == 10 || file[2] == 11)) return TRGL_E_INVALID;   // :113-116
+    *width = w; *height = h; *bpp = b;
+    return TRGL_OK;
+}
+
+int trgl_tga_decode(const uint8_t* file, size_t size, uint8_t* pixels) {
+    if (!file || !pixels) return TRGL_E_INVALID;
+    TGAImage img;
+    if (!img.decode_tga(file, size)) return TRGL_E_INVALID;
+    std::memcpy(pixels, img.buffer(), size_t(img.width()) * img.height() * img.bytespp());
+    return TRGL_OK;
+}
+
 int trgl_selftest_division(trgl_ctx* c, uint64_t samples, uint64_t seed, uint64_t* mismatches) {
     CHKCTX(c);
     if (!mismatches) return fail(c, TRGL_E_INVALID, "null mismatches");

@@ -2,11 +2,12 @@
 // byte-exact TGA file format of its writer (tgaimage.cpp:161-242): 18-byte header, no footer,
 // imagedescriptor 0x00 when vflip (the default), RLE packets formed exactly as the reference forms
 // them (its raw packets run up to AND INCLUDING the first pixel of the next repeated pair).
-// Host-only; this is SURVEY.md §8(f) row N3.
+// The reader follows read_tga_file / load_rle_data (tgaimage.cpp:76-160).  Host-only; this is SURVEY.md §8(f) row N3.
 #pragma once
 #include <cstdint>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <string>
 #include <vector>
 
@@ -96,36 +97,58 @@ public:
         out.write(reinterpret_cast<const char*>(bytes.data()), std::streamsize(bytes.size()));
         return bool(out);
     }
+    // TGAImage::read_tga_file (tgaimage.cpp:76-126) + load_rle_data (:128-160) on a file image in memory, with the
+    // reference's std::ifstream behaviour spelled out: a short read delivers what is there and fails the stream, after
+    // which every read is a no-op - so a truncated raw image keeps zeros, a truncated RLE stream repeats the last
+    // colour read (chunk headers then read as 0 = one raw pixel), and neither is an error.  Errors (false) are: header
+    // shorter than 18 bytes, width/height 0, bits per pixel not 8/24/32, data type not 2/3/10/11, and an RLE packet
+    // running past the last pixel (the reference writes one pixel out of bounds before it notices; that write is not
+    // reproduced).
+    bool decode_tga(const std::uint8_t* file, std::size_t size) {
+        data.clear();
+        std::size_t pos = 0; bool good = true;
+        auto rd = [&](std::uint8_t* dst, std::size_t k) {
+            if (!good) return;
+            std::size_t avail = pos < size ? size - pos : 0, m = k < avail ? k : avail;
+            if (m) std::memcpy(dst, file + pos, m);
+            pos += m;
+            if (m < k) good = false;
+        };
+        std::uint8_t hd[18] = { 0 };
+        rd(hd, 18);
+        if (!good) return false;                                             // :86-90
+        w = hd[12] | (hd[13] << 8); h = hd[14] | (hd[15] << 8); bpp = std::uint8_t(hd[16] >> 3);   // :92-94
+        if (w <= 0 || h <= 0 || (bpp != 1 && bpp != 3 && bpp != 4)) return false;                // :96-99
+        data.assign(std::size_t(w) * h * bpp, 0);                            // :101
+        pos += hd[0];                                                        // :103 seekg(idlength, cur)
+        if (hd[2] == 2 || hd[2] == 3) {
+            rd(data.data(), data.size());                                    // :105-108
+        } else if (hd[2] == 10 || hd[2] == 11) {
+            const int npix = w * h;
+            int cur = 0;
+            TGAColor c;                                                      // :132, {0,0,0,255}
+            while (cur < npix) {
+                std::uint8_t head = 0;
+                rd(&head, 1);
+                const bool raw = head < 128;
+                const int count = raw ? head + 1 : head - 127;
+                if (!raw) rd(c.bgra, bpp);
+                for (int i = 0; i < count; ++i) {
+                    if (raw) rd(c.bgra, bpp);
+                    if (cur >= npix) return false;                           // :145 / :155
+                    std::memcpy(&data[std::size_t(cur++) * bpp], c.bgra, bpp);
+                }
+            }
+        } else return false;                                                 // :113-116
+        if (!(hd[17] & 0x20)) flip_vertically();                             // :118
+        if (hd[17] & 0x10) flip_horizontally();                              // :119
+        return true;
+    }
     bool read_tga_file(const std::string& filename) {
         std::ifstream in(filename, std::ios::binary);
         if (!in.is_open()) return false;
-        std::uint8_t hd[18];
-        in.read(reinterpret_cast<char*>(hd), 18);
-        if (!in.good()) return false;
-        w = hd[12] | (hd[13] << 8); h = hd[14] | (hd[15] << 8); bpp = hd[16] >> 3;
-        if (w <= 0 || h <= 0 || (bpp != 1 && bpp != 3 && bpp != 4)) return false;
-        data.assign(std::size_t(w) * h * bpp, 0);
-        in.seekg(hd[0], std::ios::cur);
-        if (hd[2] == 2 || hd[2] == 3) {
-            in.read(reinterpret_cast<char*>(data.data()), std::streamsize(data.size()));
-        } else if (hd[2] == 10 || hd[2] == 11) {
-            int npix = w * h, cur = 0;
-            std::uint8_t px[4];
-            while (cur < npix) {
-                int head = in.get();
-                if (head < 0) return false;
-                int count = head < 128 ? head + 1 : head - 127;
-                if (head >= 128) in.read(reinterpret_cast<char*>(px), bpp);
-                for (int i = 0; i < count; ++i) {
-                    if (head < 128) in.read(reinterpret_cast<char*>(px), bpp);
-                    if (cur >= npix) return false;
-                    std::memcpy(&data[std::size_t(cur++) * bpp], px, bpp);
-                }
-            }
-        } else return false;
-        if (!(hd[17] & 0x20)) flip_vertically();
-        if (hd[17] & 0x10) flip_horizontally();
-        return true;
+        std::vector<std::uint8_t> bytes((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        return decode_tga(bytes.data(), bytes.size());
     }
 
 private:
