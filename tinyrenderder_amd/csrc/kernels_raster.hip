@@ -458,7 +458,7 @@ __device__ __forceinline__ void tile_clear_color(const FrameParams& fp, int lane
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND != KIND_ANY ? 4 : 3, KIND != KIND_ANY ? 4 : 3))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
+__global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(KIND != KIND_ANY ? 4 : 3, KIND != KIND_ANY ? 4 : 3))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
                                                 const uint32_t* __restrict__ tile_start,
                                                 const uint32_t* __restrict__ tile_end,
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND != KIN
 // barycentrics are recomputed per pixel with exactly the operations of the scan (same bits).
 // ---------------------------------------------------------------------------------------------
 template <int KIND>
-__global__ __launch_bounds__(256) void k_shade(FrameParams fp, const TriRec* __restrict__ recs, const DrawDesc* __restrict__ draws,
+__global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) void k_shade(FrameParams fp, const TriRec* __restrict__ recs, const DrawDesc* __restrict__ draws,
                                                 const DevTexture* __restrict__ tex, const uint32_t* __restrict__ tile_start,
                                                 const uint32_t* __restrict__ tile_end, const uint32_t* __restrict__ items,
                                                 const uint32_t* __restrict__ n_items) {
@@ -969,7 +969,7 @@ void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER
     hipLaunchKernelGGL(k_make_items, dim3((tiles + 255) / 256), dim3(256), 0, s, fp, tile_start, tile_end, split_len, items, n_items);
     dim3 grid((max_items + TRGL_WAVES_PER_BLOCK - 1) / TRGL_WAVES_PER_BLOCK);
     if (ev_before) (void)hipEventRecord(ev_before, s);
-#define TRGL_LAUNCH_RASTER(K) hipLaunchKernelGGL(k_raster<K>, grid, dim3(256), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items, item_stats)
+#define TRGL_LAUNCH_RASTER(K) hipLaunchKernelGGL(k_raster<K>, grid, dim3(64 * TRGL_WAVES_PER_BLOCK), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items, item_stats)
     switch (kind) {
     case TRGL_SHADER_FLAT:    TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT); break;
     case TRGL_SHADER_GOURAUD: TRGL_LAUNCH_RASTER(TRGL_SHADER_GOURAUD); break;
@@ -979,8 +979,8 @@ void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER
     }
 #undef TRGL_LAUNCH_RASTER
     if (ev_after) (void)hipEventRecord(ev_after, s);
-    if (kind == TRGL_SHADER_PHONG) hipLaunchKernelGGL(k_shade<TRGL_SHADER_PHONG>, grid, dim3(256), 0, s, fp, recs, draws, tex, tile_start, tile_end, items, n_items);
-    if (kind == TRGL_SHADER_EYE) hipLaunchKernelGGL(k_shade<TRGL_SHADER_EYE>, grid, dim3(256), 0, s, fp, recs, draws, tex, tile_start, tile_end, items, n_items);
+    if (kind == TRGL_SHADER_PHONG) hipLaunchKernelGGL(k_shade<TRGL_SHADER_PHONG>, grid, dim3(64 * TRGL_WAVES_PER_BLOCK), 0, s, fp, recs, draws, tex, tile_start, tile_end, items, n_items);
+    if (kind == TRGL_SHADER_EYE) hipLaunchKernelGGL(k_shade<TRGL_SHADER_EYE>, grid, dim3(64 * TRGL_WAVES_PER_BLOCK), 0, s, fp, recs, draws, tex, tile_start, tile_end, items, n_items);
     hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(1024), 0, s, stats, n_items, item_stats);
 }
 
