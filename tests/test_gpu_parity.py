@@ -113,6 +113,43 @@ def test_c4_full_size_properties():
     assert st[0] == N and st[2:6] == (0, 0, W - 1, H - 1) and st[1] > 0 and -1.0 <= st[6] < st[7] <= 1.0
 
 
+def test_c5_8192_eight_strips_compose():
+    """BASELINE config 4 shape on one GPU: an 8192x8192 frame cut into the 8 horizontal strips the 8 ranks of
+    `bench.py --gpus 8` own, rendered one after the other by strip contexts, equals the unsharded frame: rows,
+    depths, summed fragment counts, z range.  (What RCCL then does with the strips is a plain all-gather.)
+    The oracle confirms a 200k-triangle prefix of the same scene on the first strip's rows."""
+    import torch
+    W = H = 8192
+    N, G = 2_000_000, 8
+    clip, col = scenes.random_triangles(N, W, H, seed=0x5EED0005, rmin=2, rmax=40)
+    dclip = torch.from_numpy(clip).cuda()
+    dcol = torch.from_numpy(col.view(np.int32)).cuda()
+    with Context(W, H, 3) as ctx:
+        ctx.draw(FLAT, dclip, colors=dcol, device=True)
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    frags, zmin, zmax = 0, np.inf, -np.inf
+    for g in range(G):
+        y0, y1 = H * g // G, H * (g + 1) // G
+        with Context(W, H, 3) as ctx:
+            ctx.set_strip(y0, y1)
+            ctx.draw(FLAT, dclip, colors=dcol, device=True)
+            sfb, sz, sst = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+        assert np.array_equal(sfb[y0:y1], fb[y0:y1]), f"strip {g}: colours"
+        assert np.array_equal(sz[y0:y1].view(np.uint64), z[y0:y1].view(np.uint64)), f"strip {g}: depths"
+        assert sst[0] == st[0] and sst[2:6] == st[2:6]
+        frags += sst[1]; zmin = min(zmin, sst[6]); zmax = max(zmax, sst[7])
+    assert (frags, zmin, zmax) == (st[1], st[6], st[7])
+    M = 200_000
+    with Context(W, H, 3) as ctx:
+        ctx.set_strip(0, H // G)
+        ctx.draw(FLAT, clip[:M], colors=col[:M])
+        pfb, pz, pst = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    o = orc.Oracle(W, H, 3, strip=(0, H // G))
+    o.draw(orc.FLAT, clip[:M], colors=col[:M])
+    assert np.array_equal(pfb[:H // G], o.fb[:H // G]) and np.array_equal(pz[:H // G].view(np.uint64), o.z[:H // G].view(np.uint64))
+    assert pst == o.stats
+
+
 def test_readback_roundtrip_and_zbuffer_restore():
     """main.cpp:700,730 copies the z-buffer before the eyes pass and restores it afterwards."""
     case = cases.CASES["flat_small_64"]()
