@@ -2,6 +2,7 @@
 # Detailed SQ counters of the raster kernel (two passes of 8 SQ counters each), default bench workload.
 set -e
 OUT=gpurun_out/pmc_raster_${1:-x}
+rm -rf $OUT
 mkdir -p $OUT; export TMPDIR=/tmp
 ARGS="bench.py --steps 3 --warmup 1 --cpu-sample 0 --writeout-frames 0"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_BRANCH --output-format csv -d $OUT/a -- python3 $ARGS > $OUT/a.log 2>&1

@@ -5,6 +5,7 @@
 set -e
 TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="bench.py --steps 3 --warmup 1 --cpu-sample 0 --writeout-frames 0"

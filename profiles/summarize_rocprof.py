@@ -24,14 +24,20 @@ def short(name):
 
 
 print("== kernel trace stats (rocprofv3 --kernel-trace --stats) ==")
-for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+def newest(pattern):
+    """the most recent match only (a re-used output directory keeps the files of earlier runs)"""
+    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return files[-1:]
+
+
+for f in newest(os.path.join(out, "trace", "**", "*kernel_stats.csv")):
     rows = list(csv.DictReader(open(f)))
     print(f"{'kernel':28s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'%':>6s}")
     for r in rows:
         print(f"{short(r['Name']):28s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:10.3f} {float(r['AverageNs'])/1e3:10.1f} "
               f"{float(r['MinNs'])/1e3:10.1f} {float(r['MaxNs'])/1e3:10.1f} {float(r['Percentage']):6.2f}")
 
-for f in glob.glob(os.path.join(out, "trace_writeout", "**", "*kernel_stats.csv"), recursive=True):
+for f in newest(os.path.join(out, "trace_writeout", "**", "*kernel_stats.csv")):
     print("\n== write-out-only frames at 4096x4096 (profiles/writeout_probe.py 4096: RGB then RGBA framebuffer, 25 frames each) ==")
     for r in csv.DictReader(open(f)):
         if "k_raster" in r["Name"]:
@@ -43,7 +49,7 @@ for f in glob.glob(os.path.join(out, "trace_writeout", "**", "*kernel_stats.csv"
         print("\n".join(l for l in open(log).read().splitlines() if l[:1].isdigit()))
 
 for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    files = glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True)
+    files = newest(os.path.join(out, tag, "**", "*counter_collection.csv"))
     if not files:
         continue
     acc = defaultdict(lambda: defaultdict(list))
@@ -58,7 +64,7 @@ for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
 # FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) reads.
 def per_launch(tag, counter, kernel="k_raster"):
     vals = []
-    for f in glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(out, tag, "**", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 vals.append(float(r["Counter_Value"]))
