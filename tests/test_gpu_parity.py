@@ -113,6 +113,27 @@ def test_c4_full_size_properties():
     assert st[0] == N and st[2:6] == (0, 0, W - 1, H - 1) and st[1] > 0 and -1.0 <= st[6] < st[7] <= 1.0
 
 
+def test_two_phong_draws_in_one_flush_and_strips():
+    """The deferred PHONG path (k_raster visibility + k_shade) with TWO PHONG draws of different uniforms / varyings in one
+    flush (k_shade serves one draw at a time inside a wave), whole frame and cut into strips of odd heights (row bands,
+    strip-clipped tiles), against the oracle."""
+    from tinyrenderder_amd.api import PHONG, make_uniforms
+    w, h = 320, 200
+    hd = scenes.head_standin(3, w, h)
+    big = scenes.head_standin(2, w, h, seed=99, distance=1.6)
+    d, n, sp = scenes.procedural_textures(128)
+    u_bg = make_uniforms(big["model_view"], big["key"], big["fill"], big["rim"], 0.5, 0, 1, -1)
+    u_hd = make_uniforms(hd["model_view"], hd["key"], hd["fill"], hd["rim"], 1.0, 0, 1, 2)
+    case = cases._case(w, h, [(PHONG, u_bg, big["clip"], big["varyings"], None), (PHONG, u_hd, hd["clip"], hd["varyings"], None)],
+                       textures={0: d, 1: n, 2: sp}, clear=(30, 20, 10, 255))
+    ofb, oz, ost = cases.run_oracle(case)
+    fb, z, st, _ = cases.run_gpu(case)
+    assert np.array_equal(z.view(np.uint64), oz.view(np.uint64)) and np.array_equal(fb, ofb) and st == ost
+    for y0, y1 in ((0, 77), (77, 131), (131, h)):
+        sfb, sz, _, _ = cases.run_gpu(case, strip=(y0, y1))
+        assert np.array_equal(sfb[y0:y1], ofb[y0:y1]) and np.array_equal(sz[y0:y1].view(np.uint64), oz[y0:y1].view(np.uint64))
+
+
 def test_c5_8192_eight_strips_compose():
     """BASELINE config 4 shape on one GPU: an 8192x8192 frame cut into the 8 horizontal strips the 8 ranks of
     `bench.py --gpus 8` own, rendered one after the other by strip contexts, equals the unsharded frame: rows,
