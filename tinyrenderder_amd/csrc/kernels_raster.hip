@@ -336,44 +336,44 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                 const double z = b0 * T.z0 + b1 * T.z1 + b2 * T.z2;           // :156-158
                 // :160 — checked on both paths: the NDC depths of a well-scaled triangle are finite but not bounded
                 if (__builtin_isfinite(z) && (z < zold)) {                    // :160, :165
+                    // PHONG / EYE fragments are not shaded here: the pixel remembers which triangle owns it and k_shade
+                    // runs the fragment shader once per visible pixel when the list is done (the shaders have no side
+                    // effects, so the image is the same as shading every z-pass in order, and the counters do not depend
+                    // on colours).  FLAT / GOURAUD colours are stored at once (and, in a mixed flush, disown the pixel).
                     uint32_t color = 0;
-                    constexpr bool DEFERRED = KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE;
+                    bool shade_later = KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE;      // wave-uniform
                     if (FLAT_ONLY) {
                         color = T.color;
-                    } else if (DEFERRED) {
-                        // visibility only: remember which triangle owns the pixel; k_shade runs the fragment shader once
-                        // per visible pixel when the list is done (the shaders have no side effects, so the image is the
-                        // same as shading every z-pass in order, and the counters do not depend on colours)
-                        S.id_lane[(size_t)(8 * cy) * S.row_px + (size_t)(8 * cx)] = bcast_u(tri_l, j);
-                    } else {
+                    } else if (KIND == TRGL_SHADER_GOURAUD || KIND == KIND_ANY) {
                         const DrawDesc& d = draws[T.dl >> 24];
                         const int kind = KIND == KIND_ANY ? d.kind : KIND;
                         if (kind == TRGL_SHADER_FLAT) {
                             color = T.color;
-                        } else {
+                        } else if (kind == TRGL_SHADER_GOURAUD) {
                             double pc[3];
                             const double denom = b0 * T.iw0 + b1 * T.iw1 + b2 * T.iw2;            // :172-174
                             if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }      // :177-185
                             else { pc[0] = (b0 * T.iw0) / denom; pc[1] = (b1 * T.iw1) / denom; pc[2] = (b2 * T.iw2) / denom; }
-                            if (KIND != TRGL_SHADER_GOURAUD) {
+                            if (KIND == KIND_ANY) {
                                 const uint32_t local = T.dl & 0xffffffu;
-                                const double* vary = d.vary + (size_t)local * (KIND == KIND_ANY ? d.K : 24);
-                                if (kind == TRGL_SHADER_GOURAUD) color = frag_gouraud(d.colors ? d.colors[local] : 0xffffffffu, vary, pc);
-                                else if (kind == TRGL_SHADER_PHONG) color = frag_phong(d.u, tex, vary, pc).bgra;
-                                else color = frag_eye(d.u, tex, vary, pc).bgra;
+                                color = frag_gouraud(d.colors ? d.colors[local] : 0xffffffffu, d.vary + (size_t)local * d.K, pc);
                             } else {
                                 double vary[3];
                                 vary[0] = bcast_d(V.v[0].x, V.v[0].y, j); vary[1] = bcast_d(V.v[0].z, V.v[0].w, j);
                                 vary[2] = bcast_d(V.v[1].x, V.v[1].y, j);
                                 color = frag_gouraud(bcast_u(V.color, j), vary, pc);
                             }
+                        } else {
+                            shade_later = true;
                         }
                     }
+                    if (KIND >= TRGL_SHADER_PHONG && S.id_lane)               // a flush with PHONG / EYE draws (wave-uniform)
+                        S.id_lane[(size_t)(8 * cy) * S.row_px + (size_t)(8 * cx)] = shade_later ? bcast_u(tri_l, j) : 0xffffffffu;
 #ifdef TRGL_DEBUG_COUNTERS
                     if (dropped) TRGL_DBG(7, 1);                              // must stay 0
 #endif
                     S.zt[li] = z;                                             // :191
-                    if (!DEFERRED) {                                          // :192, tgaimage.cpp:32-39: straight to the framebuffer
+                    if (!shade_later) {                                       // :192, tgaimage.cpp:32-39: straight to the framebuffer
                         uint8_t* dst = S.fb_lane + ((size_t)(8 * cy) * S.row_bytes + (size_t)(8 * cx) * S.bpp);
                         if (S.bpp == 3) { dst[0] = (uint8_t)color; dst[1] = (uint8_t)(color >> 8); dst[2] = (uint8_t)(color >> 16); }
                         else if (S.bpp == 4) *reinterpret_cast<uint32_t*>(dst) = color;
@@ -458,7 +458,7 @@ __device__ __forceinline__ void tile_clear_color(const FrameParams& fp, int lane
 }
 
 template <int KIND>
-__global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(KIND != KIND_ANY ? 4 : 3, KIND != KIND_ANY ? 4 : 3))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
+__global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
                                                 const uint32_t* __restrict__ tile_start,
                                                 const uint32_t* __restrict__ tile_end,
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     // straight into the framebuffer (TGAImage::set, tgaimage.cpp:32-39).  With aligned blocks the same lane owns a
     // pixel every time, so successive writes to a pixel are same-thread, same-address stores and keep program order.
     // 8.6 KB of LDS per wave instead of 12.6 KB = 16 waves per CU instead of 12, and no colour tile in / out.
-    constexpr bool DEFERRED = KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE;
+    const bool DEFERRED = fp.idbuf != nullptr;           // the flush has PHONG / EYE draws (trgl_flush)
     if (DEFERRED) {                                      // visibility buffer of the rows this item owns: no owner yet
         for (int r2 = 0; r2 < TRGL_TILE; r2 += 2) {
             const int x = px0 + (lane & 31), y = py0 + r2 + (lane >> 5);
@@ -815,7 +815,8 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) void k_shade(FrameParams
             if (here) {
                 const DrawDesc& d = draws[di];
                 const double* vary = d.vary + (size_t)(dl & 0xffffffu) * 24;
-                color = KIND == TRGL_SHADER_PHONG ? frag_phong(d.u, tex, vary, pc).bgra : frag_eye(d.u, tex, vary, pc).bgra;
+                const int kind = KIND == KIND_ANY ? d.kind : KIND;        // wave-uniform inside this iteration
+                color = kind == TRGL_SHADER_PHONG ? frag_phong(d.u, tex, vary, pc).bgra : frag_eye(d.u, tex, vary, pc).bgra;
             }
         }
         uint8_t* dst = fp.fb + idx * fp.bpp;                                               // TGAImage::set, tgaimage.cpp:32-39
@@ -979,8 +980,13 @@ void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER
     }
 #undef TRGL_LAUNCH_RASTER
     if (ev_after) (void)hipEventRecord(ev_after, s);
-    if (kind == TRGL_SHADER_PHONG) hipLaunchKernelGGL(k_shade<TRGL_SHADER_PHONG>, grid, dim3(64 * TRGL_WAVES_PER_BLOCK), 0, s, fp, recs, draws, tex, tile_start, tile_end, items, n_items);
-    if (kind == TRGL_SHADER_EYE) hipLaunchKernelGGL(k_shade<TRGL_SHADER_EYE>, grid, dim3(64 * TRGL_WAVES_PER_BLOCK), 0, s, fp, recs, draws, tex, tile_start, tile_end, items, n_items);
+    if (fp.idbuf) {                                     // the flush has PHONG / EYE draws: shade the visible pixels they own
+#define TRGL_LAUNCH_SHADE(K) hipLaunchKernelGGL(k_shade<K>, grid, dim3(64 * TRGL_WAVES_PER_BLOCK), 0, s, fp, recs, draws, tex, tile_start, tile_end, items, n_items)
+        if (kind == TRGL_SHADER_PHONG) TRGL_LAUNCH_SHADE(TRGL_SHADER_PHONG);
+        else if (kind == TRGL_SHADER_EYE) TRGL_LAUNCH_SHADE(TRGL_SHADER_EYE);
+        else TRGL_LAUNCH_SHADE(KIND_ANY);
+#undef TRGL_LAUNCH_SHADE
+    }
     hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(1024), 0, s, stats, n_items, item_stats);
 }
 

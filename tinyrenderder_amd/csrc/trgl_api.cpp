@@ -420,7 +420,9 @@ int trgl_flush(trgl_ctx* c) {
 
     int flush_kind = c->draws.empty() ? TRGL_SHADER_FLAT : c->draws[0].kind;     // one kind for the whole flush, or -1
     for (auto& d : c->draws) if (d.kind != flush_kind) flush_kind = -1;
-    if (flush_kind == TRGL_SHADER_PHONG || flush_kind == TRGL_SHADER_EYE) {       // shaded once per visible pixel (k_shade)
+    bool shade_later = false;
+    for (auto& d : c->draws) if (d.kind == TRGL_SHADER_PHONG || d.kind == TRGL_SHADER_EYE) shade_later = true;
+    if (shade_later) {                                                            // shaded once per visible pixel (k_shade)
         if ((r = grow(c, c->idbuf, c->cap_idbuf, (size_t)c->W * c->H))) return r;
         fp.idbuf = c->idbuf;
     }
