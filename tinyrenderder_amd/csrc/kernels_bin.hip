@@ -227,6 +227,27 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const uint32_t* __
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
+// small inputs (a mesh frame's radix histograms): the whole exclusive scan in ONE block, chunk after chunk with a carry,
+// instead of three launches
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_single(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out,
+                                                               unsigned long long* __restrict__ total64) {
+    __shared__ uint32_t smem[4];
+    unsigned long long running = 0;
+    for (uint32_t start = 0; start < n; start += SCAN_ELEMS) {
+        const uint32_t base = start + threadIdx.x * SCAN_PER_THREAD;
+        uint32_t v[SCAN_PER_THREAD], sum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER_THREAD; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; sum += v[k]; }
+        uint32_t tot;
+        uint32_t run = block_excl_scan(sum, smem, &tot) + (uint32_t)running;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER_THREAD; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+        running += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total64) *total64 = running;
+}
+
 // single block: exclusive scan of the block sums in place; grand total (64-bit) to *total64
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_spine(uint32_t* __restrict__ block_sums, uint32_t nblocks,
                                                               unsigned long long* __restrict__ total64) {
@@ -475,6 +496,10 @@ void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uin
                            unsigned long long* total64) {
     if (!n) { if (total64) (void)hipMemsetAsync(total64, 0, 8, s); return; }
     uint32_t nb = scan_num_blocks(n);
+    if (nb <= 16) {                      // <= 65536 elements: one launch
+        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(SCAN_THREADS), 0, s, in, (uint32_t)n, out, total64);
+        return;
+    }
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, block_sums);
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(SCAN_THREADS), 0, s, block_sums, nb, total64);
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, block_sums, out);

@@ -904,7 +904,7 @@ __global__ __launch_bounds__(256) void k_make_items(FrameParams fp, const uint32
 
 // after the raster kernel of a flush: fold the per-item partials into the context's counters (our_gl.cpp:194-198)
 // and fix the sign of a zero z-range end (see DevStats).  One block.
-__global__ __launch_bounds__(1024) void k_fold_stats(DevStats* __restrict__ s, const uint32_t* __restrict__ n_items,
+__global__ __launch_bounds__(1024) void k_fold_stats(DevStats* __restrict__ s, uint32_t* __restrict__ n_items,
                                                      const unsigned long long* __restrict__ item_stats) {
     __shared__ unsigned long long sh[3][16];
     const uint32_t n = *n_items;
@@ -937,6 +937,7 @@ __global__ __launch_bounds__(1024) void k_fold_stats(DevStats* __restrict__ s, c
         }
         s->zero_pos_key = TRGL_ZERO_KEY_EMPTY;
         s->zero_neg_key = TRGL_ZERO_KEY_EMPTY;
+        *n_items = 0;           // every thread read it before the barrier; k_make_items of the next flush appends from 0
     }
 }
 
@@ -966,7 +967,6 @@ void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER
         if (ev_after) (void)hipEventRecord(ev_after, s);
         return;
     }
-    (void)hipMemsetAsync(n_items, 0, 4, s);
     hipLaunchKernelGGL(k_make_items, dim3((tiles + 255) / 256), dim3(256), 0, s, fp, tile_start, tile_end, split_len, items, n_items);
     dim3 grid((max_items + TRGL_WAVES_PER_BLOCK - 1) / TRGL_WAVES_PER_BLOCK);
     if (ev_before) (void)hipEventRecord(ev_before, s);

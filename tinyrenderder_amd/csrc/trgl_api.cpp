@@ -154,9 +154,10 @@ int trgl_create(int device, int width, int height, int bpp, trgl_ctx** out) {
     CRE(hipMalloc((void**)&c->zb, npx * sizeof(double)));
     CRE(hipMalloc((void**)&c->tex_dev, sizeof(c->tex_host)));
     CRE(hipMemset(c->tex_dev, 0, sizeof(c->tex_host)));
-    CRE(hipMalloc((void**)&c->tile_start, ntiles * 4));
-    CRE(hipMalloc((void**)&c->tile_end, ntiles * 4));
+    CRE(hipMalloc((void**)&c->tile_start, ntiles * 8));        // tile_start[ntiles] followed by tile_end[ntiles]: one memset per flush
+    c->tile_end = c->tile_start + ntiles;
     CRE(hipMalloc((void**)&c->n_items, 4));
+    CRE(hipMemset(c->n_items, 0, 4));                           // k_fold_stats leaves it at 0 for the next flush
     CRE(hipMalloc((void**)&c->draws_dev, sizeof(DrawDesc) * TRGL_MAX_DRAWS));
     CRE(hipHostMalloc((void**)&c->draws_pinned, sizeof(DrawDesc) * TRGL_MAX_DRAWS));
     CRE(hipMalloc((void**)&c->stats_dev, sizeof(DevStats)));
@@ -177,7 +178,7 @@ int trgl_destroy(trgl_ctx* c) {
     for (auto& s : c->stage) (void)hipFree(s.base);
     for (int i = 0; i < TRGL_MAX_TEXTURES; ++i) if (c->tex_host[i].data) (void)hipFree((void*)c->tex_host[i].data);
     void* ptrs[] = { c->fb, c->zb, c->tex_dev, c->recs, c->cnt, c->idbuf, c->blk_sums, c->chunk_off, c->tilebox, c->keys[0], c->keys[1], c->vals[0],
-                     c->vals[1], c->hist, c->scan_tmp, c->tile_start, c->tile_end, c->draws_dev, c->stats_dev, c->items, c->n_items, c->item_stats };
+                     c->vals[1], c->hist, c->scan_tmp, c->tile_start, c->draws_dev, c->stats_dev, c->items, c->n_items, c->item_stats };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->draws_pinned) (void)hipHostFree(c->draws_pinned);
     if (c->stats_pinned) (void)hipHostFree(c->stats_pinned);
@@ -461,8 +462,7 @@ int trgl_flush(trgl_ctx* c) {
     } else if (c->profiling) {
         HIPCHK(c, hipEventRecord(c->ev[1], s));
     }
-    HIPCHK(c, hipMemsetAsync(c->tile_start, 0, ntiles * 4, s));
-    HIPCHK(c, hipMemsetAsync(c->tile_end, 0, ntiles * 4, s));
+    HIPCHK(c, hipMemsetAsync(c->tile_start, 0, ntiles * 8, s));                // tile_start and tile_end
     int cur = 0;
     if (P) {
         if (P > c->cap_pairs) {
