@@ -758,17 +758,17 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
 // k_raster left, for every pixel whose depth it wrote in this flush, the record index of the LAST triangle that passed the
 // z-test there (fp.idbuf).  IShader::fragment has no side effects and always returns discard = false (main.cpp:92-170,
 // 220-261), so calling it for that triangle only gives the same framebuffer as calling it for every z-pass in order
-// (our_gl.cpp:187-192) - with 64 busy lanes per wave instead of the few pixels of one small triangle.  One wave per
-// work item of k_raster (so tiles this flush did not touch are not visited), 16 aligned 8x8 blocks each; the
+// (our_gl.cpp:187-192) - with 64 busy lanes per wave instead of the few pixels of one small triangle.  One 256-thread
+// block per work item of k_raster (so tiles this flush did not touch are not visited), a row of 4 aligned 8x8 blocks per wave; the
 // barycentrics are recomputed per pixel with exactly the operations of the scan (same bits).
 // ---------------------------------------------------------------------------------------------
 template <int KIND>
-__global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) void k_shade(FrameParams fp, const TriRec* __restrict__ recs, const DrawDesc* __restrict__ draws,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade(FrameParams fp, const TriRec* __restrict__ recs, const DrawDesc* __restrict__ draws,
                                                 const DevTexture* __restrict__ tex, const uint32_t* __restrict__ tile_start,
                                                 const uint32_t* __restrict__ tile_end, const uint32_t* __restrict__ items,
                                                 const uint32_t* __restrict__ n_items) {
     const int lane = threadIdx.x & 63;
-    const uint32_t item_idx = blockIdx.x * TRGL_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const uint32_t item_idx = blockIdx.x;                // one 256-thread block per work item: wave w shades block row w
     if (item_idx >= *n_items) return;
     const uint32_t item = items[item_idx];
     const int t = (int)(item & 0xffffffu);
@@ -780,7 +780,8 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) void k_shade(FrameParams
     const int xa1 = min(px0 + TRGL_TILE - 1, fp.W - 1);
     const int ya0 = max(py0 + band * band_rows, fp.strip_y0);
     const int ya1 = min(min(py0 + (band + 1) * band_rows - 1, fp.H - 1), fp.strip_y1 - 1);
-    for (int k = 0; k < 16; ++k) {
+    const int krow = 4 * (int)(threadIdx.x >> 6);
+    for (int k = krow; k < krow + 4; ++k) {
         const int x = px0 + 8 * (k & 3) + (lane & 7), y = py0 + 8 * (k >> 2) + (lane >> 3);
         const bool mine = x <= xa1 && y >= ya0 && y <= ya1;
         const size_t idx = (size_t)x + (size_t)y * fp.W;
@@ -981,7 +982,7 @@ void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER
 #undef TRGL_LAUNCH_RASTER
     if (ev_after) (void)hipEventRecord(ev_after, s);
     if (fp.idbuf) {                                     // the flush has PHONG / EYE draws: shade the visible pixels they own
-#define TRGL_LAUNCH_SHADE(K) hipLaunchKernelGGL(k_shade<K>, grid, dim3(64 * TRGL_WAVES_PER_BLOCK), 0, s, fp, recs, draws, tex, tile_start, tile_end, items, n_items)
+#define TRGL_LAUNCH_SHADE(K) hipLaunchKernelGGL(k_shade<K>, dim3(max_items), dim3(256), 0, s, fp, recs, draws, tex, tile_start, tile_end, items, n_items)
         if (kind == TRGL_SHADER_PHONG) TRGL_LAUNCH_SHADE(TRGL_SHADER_PHONG);
         else if (kind == TRGL_SHADER_EYE) TRGL_LAUNCH_SHADE(TRGL_SHADER_EYE);
         else TRGL_LAUNCH_SHADE(KIND_ANY);
