@@ -1,14 +1,16 @@
 // kernels_raster.hip — the tile rasterizer (gfx950): bounding-box scan, barycentric coverage test,
 // fp64 z-test and the fragment shader of our_gl.cpp:147-199, one WAVEFRONT per 32x32 screen tile.
 //
-// The tile's z-buffer (fp64) and colour (packed BGRA) live in LDS for the whole tile, so the
-// compare-and-write of our_gl.cpp:165,191-192 needs no atomics: one wave walks the tile's triangle
-// list in submission order and, within one triangle, every lane owns a different pixel.  The tile
-// leaves the chip once, with row-contiguous stores.
+// The tile's z-buffer (fp64) lives in LDS for the whole tile, so the compare-and-write of
+// our_gl.cpp:165,191 needs no atomics: one wave walks the tile's triangle list in submission order
+// and, within one triangle, every lane owns a different pixel.  Depths leave the chip once, with
+// row-contiguous stores; colours go straight to the framebuffer as fragments pass (FLAT, GOURAUD)
+// or are shaded once per visible pixel afterwards (PHONG, EYE: k_shade).
 //
-// Arithmetic is the reference's, operation for operation, in fp64 with contraction off; the three
-// IEEE divisions per pixel of barycentric() (our_gl.cpp:85) are kept because the `>= 0` coverage
-// test and the written z depend on their rounding.
+// Arithmetic is the reference's, operation for operation, in fp64 with contraction off.  The three
+// IEEE divisions per pixel of barycentric() (our_gl.cpp:85) matter because the `>= 0` coverage test
+// and the written z depend on their rounding; for well-scaled triangles the same bits come from sign
+// tests and FMA divisions by the per-triangle constant u.z ("exactness").
 #include <hip/hip_runtime.h>
 #include "trgl_device.h"
 #include "launch.h"
@@ -324,7 +326,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                 const int li = (256 * cy + S.lrow) + ((8 * cx) ^ S.lsw);   // = lds_index(x, y) for an aligned block
                 const double zold = S.zt[li];
                 if (__ballot(!WELL_SCALED || T.zbound < zold)) TRGL_DBG(3, 1); // blocks that reach the divisions
-                // early z, exact: every covered pixel of this triangle has z >= T.zbound (see the hierarchical-Z
+                // early z, exact: every covered pixel of this triangle has z >= T.zbound (see the block-mask
                 // comment in k_raster) and the test is a strict `<`, so a pixel with zbound >= zold cannot pass;
                 // when no covered lane is left the whole division / depth phase is skipped
                 if (!WELL_SCALED || T.zbound < zold) {
