@@ -50,7 +50,6 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
                                                          uint2* __restrict__ tilebox, DevStats* __restrict__ stats,
                                                          uint32_t* __restrict__ blk_sums, uint32_t blk_base) {
     __shared__ __attribute__((aligned(16))) double s_buf[SETUP_THREADS * 16];    // 32 KB: in [256][12], then out [256][16]
-    __shared__ uint8_t s_keep[SETUP_THREADS];
     const DrawDesc& d = draws[draw_idx];
     const uint32_t b0 = blockIdx.x * SETUP_THREADS;
     const uint32_t nb = min((uint32_t)SETUP_THREADS, d.n - b0);
@@ -148,21 +147,24 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
         cnt[d.first + i] = ntiles;
         tilebox[d.first + i] = tb;
     }
-    // ---- record stream out: nb*128 contiguous bytes, 16-B chunks XOR-swizzled in LDS so neither the
-    // per-thread writes (128-B stride) nor the linear read-out conflict on banks ------------------------
+    // ---- record stream out: each wave stages its own 64 records (8 KB) in LDS, 16-B chunks XOR-swizzled so neither the
+    // per-thread writes (128-B stride) nor the linear read-out conflict on banks, and writes them as one contiguous run.
+    // A record is only ever read through a (tile, triangle) pair: triangles without pairs (rejected, or outside this
+    // context's strip - 7 of 8 on an 8-GPU shard) need no 128-B store; which ones is a wave ballot, so the phase needs no
+    // block barrier and no LDS beyond the 32 KB staging buffer (5 blocks per CU instead of 4).
+    const uint32_t lane = tid & 63, wbase = tid & ~63u;
     {
         uint4* l4 = reinterpret_cast<uint4*>(s_buf);
         const uint4* r4 = reinterpret_cast<const uint4*>(&r);
 #pragma unroll
         for (int c = 0; c < 8; ++c) l4[tid * 8 + (c ^ (tid & 7))] = r4[c];
-        s_keep[tid] = ntiles != 0;
-        __syncthreads();
-        // a record is only ever read through a (tile, triangle) pair: triangles without pairs (rejected, or
-        // outside this context's strip — 7 of 8 on an 8-GPU shard) need no 128-B store
-        uint4* dst = reinterpret_cast<uint4*>(recs + d.first + b0);
-        for (uint32_t k = tid; k < nb * 8; k += SETUP_THREADS) {
-            uint32_t t = k >> 3, c = k & 7;
-            if (s_keep[t]) dst[k] = l4[t * 8 + (c ^ (t & 7))];
+        const unsigned long long keep = __ballot(ntiles != 0);
+        __builtin_amdgcn_wave_barrier();
+        uint4* dst = reinterpret_cast<uint4*>(recs + d.first + b0 + wbase);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const uint32_t k = lane + 64u * it, t = k >> 3, c = k & 7;            // chunk c of the wave's record t
+            if ((keep >> t) & 1ull) dst[k] = l4[(wbase + t) * 8 + (c ^ (t & 7))];
         }
     }
     // pairs of this block of 256 triangles: k_expand derives every triangle's slice of the pair list from these sums
@@ -170,8 +172,9 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
     {
         uint32_t ws = ntiles;
         for (int o = 32; o; o >>= 1) ws += __shfl_xor(ws, o);
-        __shared__ uint32_t s_ws[SETUP_THREADS / 64];
-        if ((tid & 63) == 0) s_ws[tid >> 6] = ws;
+        __syncthreads();                                   // every wave is done with the staging buffer
+        uint32_t* s_ws = reinterpret_cast<uint32_t*>(s_buf);
+        if (lane == 0) s_ws[tid >> 6] = ws;
         __syncthreads();
         if (tid == 0) blk_sums[blk_base + blockIdx.x] = s_ws[0] + s_ws[1] + s_ws[2] + s_ws[3];
     }
