@@ -120,15 +120,27 @@ def main():
         ctx.set_strip(y0, y1)
         full_fb = torch.as_tensor(_DevBuf(ctx.framebuffer_ptr, W * H * 3), device="cuda")
 
+    gather = [None]      # the RCCL all-gather of the previous frame's strips, still in flight
+
     def step():
         ctx.clear()
         ctx.draw(kind, dclip, varyings=dvary, colors=dcol, uniforms=uniforms, device=True)
-        ctx.flush()
-        if use_dist:   # join the colour strips: every rank ends with the whole TGAImage buffer
-            shard.gather_strips(full_fb, W, H, 3, rank, world)
+        if not use_dist:
+            ctx.flush()
+            return
+        # Join the colour strips: every rank ends with the whole TGAImage buffer.  The gather runs on RCCL's stream;
+        # only the raster half of the NEXT frame touches the framebuffer, so that frame's setup and binning run under it.
+        ctx.flush_begin()
+        if gather[0] is not None:
+            gather[0].wait()                     # this stream waits for the gather before the raster overwrites the strip
+        ctx.flush_end()
+        gather[0] = shard.gather_strips(full_fb, W, H, 3, rank, world, async_op=True)
 
     def fence():
         if use_dist:
+            if gather[0] is not None:
+                gather[0].wait()
+                gather[0] = None
             dist.barrier()
         torch.cuda.synchronize()
 

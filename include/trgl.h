@@ -159,6 +159,12 @@ int trgl_draw_indexed(trgl_ctx* ctx, int shader_kind, const trgl_uniforms* unifo
 
 /* Execute everything submitted so far (asynchronously on the context's stream). */
 int trgl_flush(trgl_ctx* ctx);
+/* The same in two halves, for a caller that overlaps something with the first one: trgl_flush_begin runs per-triangle
+ * setup and tile binning (neither reads nor writes the framebuffer / z-buffer), trgl_flush_end the tile raster.  Every
+ * other entry point completes a begun flush first.  bench.py: the RCCL gather of the previous frame's strips runs
+ * under the next frame's first half. */
+int trgl_flush_begin(trgl_ctx* ctx);
+int trgl_flush_end(trgl_ctx* ctx);
 /* Wait for the context's stream. */
 int trgl_sync(trgl_ctx* ctx);
 

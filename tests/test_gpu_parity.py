@@ -113,6 +113,31 @@ def test_c4_full_size_properties():
     assert st[0] == N and st[2:6] == (0, 0, W - 1, H - 1) and st[1] > 0 and -1.0 <= st[6] < st[7] <= 1.0
 
 
+def test_flush_in_two_halves():
+    """trgl_flush_begin (setup + binning) / trgl_flush_end (raster) give what trgl_flush gives; any other entry point
+    called in between completes the begun flush first (here: a second draw, then a read-back)."""
+    case = cases.CASES["flat_persp_512"]()
+    kind, u, clip, vary, col = case["draws"][0]
+    ofb, oz, ost = cases.run_oracle(case)
+    half = clip.shape[0] // 2
+    with Context(case["width"], case["height"], case["bpp"]) as ctx:
+        ctx.draw(kind, clip[:half], colors=col[:half])
+        ctx.flush_begin()
+        ctx.flush_begin()                                   # a second begin is a no-op
+        ctx.flush_end()
+        ctx.flush_end()                                     # so is a second end
+        ctx.draw(kind, clip[half:], colors=col[half:])
+        ctx.flush_begin()
+        fb = ctx.read_framebuffer()                         # completes the begun flush
+        z, st = ctx.read_zbuffer(), ctx.stats()
+    assert np.array_equal(fb, ofb) and np.array_equal(z.view(np.uint64), oz.view(np.uint64)) and st == ost
+    with Context(case["width"], case["height"], case["bpp"]) as ctx:
+        ctx.draw(kind, clip[:half], colors=col[:half])
+        ctx.flush_begin()
+        ctx.draw(kind, clip[half:], colors=col[half:])      # completes the begun flush, then queues
+        assert np.array_equal(ctx.read_framebuffer(), ofb)
+
+
 def test_two_phong_draws_in_one_flush_and_strips():
     """The deferred PHONG path (k_raster visibility + k_shade) with TWO PHONG draws of different uniforms / varyings in one
     flush (k_shade serves one draw at a time inside a wave), whole frame and cut into strips of odd heights (row bands,

@@ -24,7 +24,7 @@ MAX_TEXTURES = 16
 # every symbol include/trgl.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "trgl_create", "trgl_destroy", "trgl_last_error", "trgl_set_viewport", "trgl_init_viewport", "trgl_clear",
-    "trgl_upload_texture", "trgl_set_strip", "trgl_draw", "trgl_flush", "trgl_sync", "trgl_read_framebuffer",
+    "trgl_upload_texture", "trgl_set_strip", "trgl_draw", "trgl_flush", "trgl_flush_begin", "trgl_flush_end", "trgl_sync", "trgl_read_framebuffer",
     "trgl_write_framebuffer", "trgl_read_zbuffer", "trgl_write_zbuffer", "trgl_get_stats", "trgl_reset_stats",
     "trgl_format_stats", "trgl_framebuffer_device_ptr", "trgl_zbuffer_device_ptr", "trgl_stream", "trgl_set_stream",
     "trgl_set_profiling", "trgl_get_phase_ms", "trgl_reset_phase_ms", "trgl_get_last_flush_info",
@@ -108,6 +108,8 @@ def load_library(path: str = LIB_PATH):
     L.trgl_set_strip.argtypes = [vp, C.c_int, C.c_int]
     L.trgl_draw.argtypes = [vp, C.c_int, C.POINTER(Uniforms), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
     L.trgl_flush.argtypes = [vp]
+    L.trgl_flush_begin.argtypes = [vp]
+    L.trgl_flush_end.argtypes = [vp]
     L.trgl_sync.argtypes = [vp]
     L.trgl_read_framebuffer.argtypes = [vp, C.c_void_p]
     L.trgl_write_framebuffer.argtypes = [vp, C.c_void_p]
@@ -305,6 +307,13 @@ class Context:
 
     def flush(self):
         self._chk(self.L.trgl_flush(self.h))
+
+    def flush_begin(self):
+        """Setup + binning of what was submitted (does not touch the framebuffer / z-buffer); flush_end() runs the raster."""
+        self._chk(self.L.trgl_flush_begin(self.h))
+
+    def flush_end(self):
+        self._chk(self.L.trgl_flush_end(self.h))
 
     def sync(self):
         self._chk(self.L.trgl_sync(self.h))

@@ -49,6 +49,8 @@ struct trgl_ctx {
     int stage_hold = 0;                 // >0 while a draw call has staged data that no DrawDesc references yet
 
     TriRec* recs = nullptr; uint32_t* cnt = nullptr; uint2* tilebox = nullptr;
+    // a flush whose first half (setup + binning) has run and whose raster half is still to be launched (trgl_flush_begin)
+    struct { bool active = false; FrameParams fp; int flush_kind = 0; uint32_t P = 0; int cur = 0; uint64_t N = 0; } rp;
     uint32_t* idbuf = nullptr; size_t cap_idbuf = 0;        // visibility buffer of PHONG / EYE flushes, [H][W]
     uint32_t* blk_sums = nullptr; size_t cap_blk = 0;       // pairs per setup block of 256 triangles
     uint32_t* chunk_off = nullptr; size_t cap_chunk = 0;    // pairs before every 16th setup block
@@ -190,6 +192,7 @@ int trgl_destroy(trgl_ctx* c) {
 
 int trgl_set_viewport(trgl_ctx* c, const double m[16]) {
     CHKCTX(c);
+    if (c->rp.active) { int fr = trgl_flush_end(c); if (fr) return fr; }
     if (!m) return fail(c, TRGL_E_INVALID, "trgl_set_viewport: null matrix");
     if (!c->draws.empty() && std::memcmp(c->vp, m, sizeof(c->vp)) != 0) {   // rasterize() reads Viewport at call time
         int r = trgl_flush(c); if (r) return r;
@@ -209,6 +212,8 @@ int trgl_init_viewport(trgl_ctx* c, int x, int y, int w, int h) {          // ou
 
 int trgl_clear(trgl_ctx* c, const uint8_t bgra[4], double z_clear) {
     CHKCTX(c);
+    if (c->rp.active) { int fr = trgl_flush_end(c); if (fr) return fr; }
+    if (c->rp.active) { int fr = trgl_flush_end(c); if (fr) return fr; }
     if (!c->draws.empty()) { int r = trgl_flush(c); if (r) return r; }      // earlier draws come first
     static const uint8_t dflt[4] = { 0, 0, 0, 255 };                         // TGAColor(), tgaimage.h:33
     const uint8_t* p = bgra ? bgra : dflt;
@@ -220,6 +225,7 @@ int trgl_clear(trgl_ctx* c, const uint8_t bgra[4], double z_clear) {
 
 int trgl_upload_texture(trgl_ctx* c, int slot, const uint8_t* texels, int w, int h, int bpp) {
     CHKCTX(c);
+    if (c->rp.active) { int fr = trgl_flush_end(c); if (fr) return fr; }
     if (slot < 0 || slot >= TRGL_MAX_TEXTURES) return fail(c, TRGL_E_INVALID, "trgl_upload_texture: bad slot");
     if (!c->draws.empty()) { int r = trgl_flush(c); if (r) return r; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -238,6 +244,7 @@ int trgl_upload_texture(trgl_ctx* c, int slot, const uint8_t* texels, int w, int
 
 int trgl_set_strip(trgl_ctx* c, int y0, int y1) {
     CHKCTX(c);
+    if (c->rp.active) { int fr = trgl_flush_end(c); if (fr) return fr; }
     if (y0 < 0 || y1 > c->H || y0 > y1) return fail(c, TRGL_E_INVALID, "trgl_set_strip: need 0 <= y0 <= y1 <= H");
     if (!c->draws.empty()) { int r = trgl_flush(c); if (r) return r; }
     c->strip_y0 = y0; c->strip_y1 = y1;
@@ -276,6 +283,7 @@ static int stage_copy(trgl_ctx* c, const void* src, size_t bytes, void** dev) {
 int trgl_draw(trgl_ctx* c, int kind, const trgl_uniforms* u, const double* clip, const double* vary,
               const uint32_t* colors, uint64_t n, int mem_kind) {
     CHKCTX(c);
+    if (c->rp.active) { int fr = trgl_flush_end(c); if (fr) return fr; }
     if (kind < 0 || kind >= TRGL_NUM_SHADERS) return fail(c, TRGL_E_INVALID, "trgl_draw: unknown shader kind");
     if (n == 0) return TRGL_OK;
     if (!clip) return fail(c, TRGL_E_INVALID, "trgl_draw: clip is null");
@@ -315,6 +323,7 @@ int trgl_draw(trgl_ctx* c, int kind, const trgl_uniforms* u, const double* clip,
 int trgl_draw_indexed(trgl_ctx* c, int kind, const trgl_uniforms* u, const double projection[16], const double* vertices,
                       int stride, uint64_t n_vertices, const uint32_t* indices, uint64_t n_faces, int mem_kind) {
     CHKCTX(c);
+    if (c->rp.active) { int fr = trgl_flush_end(c); if (fr) return fr; }
     if (kind != TRGL_SHADER_PHONG && kind != TRGL_SHADER_EYE) return fail(c, TRGL_E_INVALID, "trgl_draw_indexed: kind must be PHONG or EYE");
     if (!u || !projection || !vertices || !indices) return fail(c, TRGL_E_INVALID, "trgl_draw_indexed: null argument");
     if (stride < 8) return fail(c, TRGL_E_INVALID, "trgl_draw_indexed: vertex stride must be >= 8 doubles (pos3, normal3, uv2)");
@@ -401,6 +410,16 @@ static int resolve_events(trgl_ctx* c) {
 
 int trgl_flush(trgl_ctx* c) {
     CHKCTX(c);
+    int r = trgl_flush_begin(c);
+    return r ? r : trgl_flush_end(c);
+}
+
+// First half of a flush: per-triangle setup and the stable tile binning.  Touches neither the framebuffer nor the
+// z-buffer, so a caller may let it overlap with whatever still reads them (bench.py: the RCCL gather of the
+// previous frame's strips).
+int trgl_flush_begin(trgl_ctx* c) {
+    CHKCTX(c);
+    if (c->rp.active) return TRGL_OK;
     if (c->draws.empty() && !c->clear_pending) return TRGL_OK;
     int r;
     if ((r = resolve_events(c))) return r;
@@ -494,6 +513,21 @@ int trgl_flush(trgl_ctx* c) {
         launch_bounds(s, c->keys[cur], P, c->tile_start, c->tile_end);
     }
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], s));
+    c->rp.active = true; c->rp.fp = fp; c->rp.flush_kind = flush_kind; c->rp.P = P; c->rp.cur = cur; c->rp.N = N;
+    return TRGL_OK;
+}
+
+// Second half: the tile raster (and k_shade), the only part that reads or writes the framebuffer and the z-buffer.
+int trgl_flush_end(trgl_ctx* c) {
+    CHKCTX(c);
+    if (!c->rp.active) return TRGL_OK;
+    c->rp.active = false;
+    int r;
+    hipStream_t s = c->stream;
+    const FrameParams fp = c->rp.fp;
+    const int flush_kind = c->rp.flush_kind, cur = c->rp.cur;
+    const uint32_t P = c->rp.P;
+    const uint64_t N = c->rp.N;
     // with no pairs every tile list is empty; the kernel must not (and does not) dereference these, but give it
     // valid addresses anyway
     const TriRec* recs_arg = c->recs ? c->recs : reinterpret_cast<const TriRec*>(c->tile_start);
@@ -537,6 +571,7 @@ int trgl_flush(trgl_ctx* c) {
 
 int trgl_sync(trgl_ctx* c) {
     CHKCTX(c);
+    if (c->rp.active) { int fr = trgl_flush_end(c); if (fr) return fr; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return TRGL_OK;
 }
@@ -679,6 +714,7 @@ int trgl_selftest_division(trgl_ctx* c, uint64_t samples, uint64_t seed, uint64_
 
 int trgl_set_stream(trgl_ctx* c, void* hip_stream, int use_own) {
     CHKCTX(c);
+    if (c->rp.active) { int fr = trgl_flush_end(c); if (fr) return fr; }
     int r = TRGL_OK;
     if (!c->draws.empty()) r = trgl_flush(c);      // a pending clear alone needs no launch: it stays pending
     if (r) return r;

@@ -19,13 +19,14 @@ def strip_rows(height: int, world: int, rank: int):
     return rank * rows, (rank + 1) * rows
 
 
-def gather_strips(full, width: int, height: int, bytes_per_pixel: int, rank: int, world: int, group=None):
-    """In-place all-gather: `full` is a flat uint8 tensor of the whole buffer whose own strip is already written."""
+def gather_strips(full, width: int, height: int, bytes_per_pixel: int, rank: int, world: int, group=None, async_op=False):
+    """In-place all-gather: `full` is a flat uint8 tensor of the whole buffer whose own strip is already written.
+    async_op=True returns the work handle (wait() on it before the strip is written again) instead of `full`."""
     import torch.distributed as dist
     y0, y1 = strip_rows(height, world, rank)
     chunk = full[y0 * width * bytes_per_pixel: y1 * width * bytes_per_pixel]
-    dist.all_gather_into_tensor(full, chunk, group=group)
-    return full
+    work = dist.all_gather_into_tensor(full, chunk, group=group, async_op=async_op)
+    return work if async_op else full
 
 
 def reduce_stats(stats, device=None, group=None):
