@@ -113,6 +113,54 @@ def test_c4_full_size_properties():
     assert st[0] == N and st[2:6] == (0, 0, W - 1, H - 1) and st[1] > 0 and -1.0 <= st[6] < st[7] <= 1.0
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_block_masks_on_adversarial_shapes(seed):
+    """Shapes chosen against the conservative per-block tests of k_raster (edge functions at block corners, depth-plane
+    minimum vs the block's stored maximum): needles with aspect ratios up to 1e7, triangles of area 1e-9..1e-4 px^2 (u.z
+    next to the 1e-12 limit), depth planes as steep as [-1, 1] across a fraction of a pixel, a vertex thousands of pixels
+    off screen, all on top of dense overdraw so that the stored maxima are low and the masks actually drop blocks.  Any
+    block dropped wrongly shows up as a missing fragment: z bits, colours and counters must equal the oracle's."""
+    rng = scenes.SplitMix64(7000 + seed)
+    W, H = 160, 96
+    n = 12000
+    clip, col = scenes.random_triangles(n, W, H, seed=7100 + seed, rmin=2, rmax=40)
+    clip = clip.copy()
+    u = rng.uniform(n * 4).reshape(n, 4)
+    ndc_px = 2.0 / W
+    for i in range(0, n, 3):                                   # every third triangle is replaced by an adversarial one
+        kind = (i // 3) % 4
+        cx, cy = clip[i, 0], clip[i, 1]
+        ang = 6.283185307179586 * u[i, 0]
+        dx, dy = np.cos(ang), np.sin(ang)
+        if kind == 0:                                          # needle: long axis 5..60 px, width 1e-6..1e-2 px
+            L = (5 + 55 * u[i, 1]) * ndc_px; wdt = 10.0 ** (-6 + 4 * u[i, 2]) * ndc_px
+            p = [(cx - L * dx, cy - L * dy), (cx + L * dx, cy + L * dy), (cx - wdt * dy, cy + wdt * dx)]
+        elif kind == 1:                                        # tiny: edges of 1e-5..1e-2 px
+            e = 10.0 ** (-5 + 3 * u[i, 1]) * ndc_px
+            p = [(cx, cy), (cx + e * dx, cy + e * dy), (cx - e * dy, cy + e * dx)]
+        elif kind == 2:                                        # ordinary footprint, depth plane as steep as it gets
+            r = (1 + 6 * u[i, 1]) * ndc_px
+            p = [(cx + r * np.cos(ang + a), cy + r * np.sin(ang + a)) for a in (0.0, 2.1, 4.2)]
+        else:                                                  # one vertex far off screen
+            r = (2 + 10 * u[i, 1]) * ndc_px; far = 50.0 + 5000.0 * u[i, 2]
+            p = [(cx, cy), (cx + r * dx, cy + r * dy), (cx - far * dy, cy + far * dx)]
+        # counter-clockwise so that the back-face test keeps it
+        (x0, y0), (x1, y1), (x2, y2) = p
+        if (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0) < 0:
+            p[1], p[2] = p[2], p[1]
+        zs = [-1.0, 1.0, -1.0 + 2.0 * u[i, 3]] if kind == 2 else [2.0 * u[i, 3] - 1.0, 2.0 * u[i, 1] - 1.0, 2.0 * u[i, 2] - 1.0]
+        for v in range(3):
+            clip[i, 4 * v + 0], clip[i, 4 * v + 1], clip[i, 4 * v + 2], clip[i, 4 * v + 3] = p[v][0], p[v][1], zs[v], 1.0
+    with Context(W, H, 3) as ctx:
+        ctx.draw(FLAT, clip, colors=col)
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    o = orc.Oracle(W, H, 3)
+    o.draw(orc.FLAT, clip, colors=col)
+    assert np.array_equal(z.view(np.uint64), o.z.view(np.uint64))
+    assert np.array_equal(fb, o.fb)
+    assert st == o.stats
+
+
 def test_flush_in_two_halves():
     """trgl_flush_begin (setup + binning) / trgl_flush_end (raster) give what trgl_flush gives; any other entry point
     called in between completes the begun flush first (here: a second draw, then a read-back)."""
