@@ -161,6 +161,27 @@ def test_block_masks_on_adversarial_shapes(seed):
     assert st == o.stats
 
 
+@pytest.mark.parametrize("bpp", [1, 4])
+def test_phong_and_eye_on_gray_and_rgba_framebuffers(bpp):
+    """TGAImage::set copies bytespp bytes of the returned colour (tgaimage.cpp:32-39): k_shade must do the same on a
+    1-byte and a 4-byte framebuffer (the golden PHONG / EYE cases are RGB)."""
+    from tinyrenderder_amd.api import PHONG, EYE, make_uniforms
+    w, h = 200, 136
+    hd = scenes.head_standin(3, w, h)
+    d, n, sp = scenes.procedural_textures(64)
+    u = make_uniforms(hd["model_view"], hd["key"], hd["fill"], hd["rim"], 1.0, 0, 1, 2)
+    for kind in (PHONG, EYE):
+        case = cases._case(w, h, [(kind, u, hd["clip"], hd["varyings"], None)], bpp=bpp, textures={0: d, 1: n, 2: sp}, clear=(30, 20, 10, 200))
+        ofb, oz, ost = cases.run_oracle(case)
+        fb, z, st, _ = cases.run_gpu(case)
+        assert np.array_equal(z.view(np.uint64), oz.view(np.uint64)) and st == ost
+        if kind == PHONG:
+            assert np.array_equal(fb, ofb)
+        else:                       # EYE: pow(x, 8) may differ in the last ulp -> at most 1 LSB on at most 0.1 % of the bytes
+            diff = np.abs(fb.astype(np.int16) - ofb.astype(np.int16))
+            assert diff.max() <= 1 and (diff != 0).mean() <= 1e-3
+
+
 def test_flush_in_two_halves():
     """trgl_flush_begin (setup + binning) / trgl_flush_end (raster) give what trgl_flush gives; any other entry point
     called in between completes the begun flush first (here: a second draw, then a read-back)."""
