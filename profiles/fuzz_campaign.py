@@ -1,0 +1,16 @@
+"""One-off differential campaign: the two randomised GPU-vs-oracle tests of tests/test_gpu_parity.py with many more seeds
+than the suite runs (python profiles/fuzz_campaign.py [n_fuzz] [n_adversarial])."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_parity as T
+nf = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+na = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+t0 = time.time(); bad = []
+for s in range(12, 12 + nf):
+    try: T.test_fuzz_flat_scenes_against_oracle(s)
+    except AssertionError as e: bad.append(("fuzz", s, str(e)[:80]))
+for s in range(6, 6 + na):
+    try: T.test_block_masks_on_adversarial_shapes(s)
+    except AssertionError as e: bad.append(("adversarial", s, str(e)[:80]))
+print(f"{nf} fuzz + {na} adversarial scenes in {time.time() - t0:.0f} s: {len(bad)} mismatching", bad[:5])
