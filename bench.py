@@ -35,23 +35,84 @@ class _DevBuf:
 
 def cpu_baseline(clip, col, W, H, sample):
     """Single-thread CPU rate on a bounded prefix of the same workload: the reference's own rasterize()
-    (oracle/_ref, built -O3 -DNDEBUG -ffp-contract=off) when it travelled to this box, else the C restatement."""
+    (oracle/_ref, built -O3 -DNDEBUG -ffp-contract=off) when it travelled to this box, else the C restatement.
+    Returns (json dict, (framebuffer, z-buffer, print_render_stats() line)): the frame the CPU rendered is the
+    checker of the parity gate (no timing is reported unless the GPU frame matches it)."""
     from oracle import orc
     n = min(sample, clip.shape[0])
     desc = (f"all {n} triangles of the same frame" if n == clip.shape[0] else f"first {n} triangles of the same scene") + ", rasterize() loop only"
     if os.path.exists(orc.REF_HARNESS_FAST):
         from tinyrenderder_amd import scenes
-        _, _, _, secs = orc.run_reference(W, H, 3, scenes.init_viewport(0, 0, W, H), [(orc.FLAT, None, clip[:n], None, col[:n])],
-                                          harness=orc.REF_HARNESS_FAST, with_time=True)
+        fb, z, line, secs = orc.run_reference(W, H, 3, scenes.init_viewport(0, 0, W, H), [(orc.FLAT, None, clip[:n], None, col[:n])],
+                                              harness=orc.REF_HARNESS_FAST, with_time=True)
         kind = "reference"
     else:
         o = orc.Oracle(W, H, 3)
         t0 = time.perf_counter()
         o.draw(orc.FLAT, clip[:n], colors=col[:n])
         secs = time.perf_counter() - t0
+        fb, z, line = o.fb, o.z, orc.format_stats_line(o.stats)
         kind = "port"
-    return {"value": n / secs, "unit": "triangles/s", "cores": 1, "kind": kind, "sample": desc,
-            "seconds": round(secs, 3), "host_cpus": os.cpu_count()}
+    return ({"value": n / secs, "unit": "triangles/s", "cores": 1, "kind": kind, "sample": desc,
+             "seconds": round(secs, 3), "host_cpus": os.cpu_count()}, (fb, z, line))
+
+
+def parity_gate(ctx, kind, dclip, dvary, dcol, uniforms, n, cpu_frame, checker, golden_name):
+    """Render the first n triangles once more, outside the timed region, through exactly the calls of step(), and
+    compare framebuffer bytes, z-buffer bits and the print_render_stats() line with the frame the CPU rendered
+    (`cpu_frame` from cpu_baseline, or None) and with the committed digests of the reference's frame
+    (tests/golden/golden_fullsize.json, when the workload is one of its cases)."""
+    import hashlib
+    ctx.reset_stats()
+    ctx.clear()
+    ctx.draw(kind, dclip[:n], varyings=None if dvary is None else dvary[:n], colors=None if dcol is None else dcol[:n],
+             uniforms=uniforms, device=True)
+    ctx.flush()
+    fb, z, line = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats_line()
+    out = {"checked": False, "triangles": int(n), "fb": None, "z": None, "stats": None, "against": [], "stats_line": line}
+    ok = True
+    if cpu_frame is not None:
+        rfb, rz, rline = cpu_frame
+        out["fb"] = bool(np.array_equal(fb, rfb))
+        out["z"] = bool(np.array_equal(z.view(np.uint64), rz.view(np.uint64)))
+        out["stats"] = bool(line == rline)
+        out["against"].append(checker)
+        out["checked"] = True
+        ok = out["fb"] and out["z"] and out["stats"]
+        if not ok:
+            out["cpu_stats_line"] = rline
+            out["fb_bytes_differing"] = int((fb != rfb).sum())
+            out["z_values_differing"] = int((z.view(np.uint64) != rz.view(np.uint64)).sum())
+    gpath = os.path.join(ROOT, "tests", "golden", "golden_fullsize.json")
+    if golden_name and os.path.exists(gpath):
+        g = json.load(open(gpath)).get(golden_name)
+        if g:
+            sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).view(np.uint8).tobytes()).hexdigest()
+            gold = {"fb": sha(fb) == g["fb"], "z": sha(z) == g["z"], "stats": line == g["stats"]}
+            out["golden"] = gold
+            out["against"].append(f"tests/golden/golden_fullsize.json[{golden_name}] (digests of the compiled reference's frame)")
+            out["checked"] = True
+            ok = ok and all(gold.values())
+    out["ok"] = bool(ok) if out["checked"] else None
+    return out, fb
+
+
+def end_to_end(ctx, kind, clip, vary, col, uniforms, frames=2):
+    """PCIe-inclusive frame: the triangle stream handed over as pageable HOST arrays (trgl_draw copies them before it
+    returns), the flush, and the read-back of the finished framebuffer.  Reported next to `value`, never as `value`."""
+    ts = []
+    for _ in range(frames + 1):
+        t0 = time.perf_counter()
+        ctx.clear()
+        ctx.draw(kind, clip, varyings=vary, colors=col, uniforms=uniforms)
+        ctx.flush()
+        ctx.read_framebuffer()
+        ts.append(time.perf_counter() - t0)
+    dt = min(ts[1:])
+    h2d = clip.nbytes + (0 if vary is None else vary.nbytes) + (0 if col is None else col.nbytes)
+    return {"ms_per_frame": dt * 1e3, "triangles_per_s": clip.shape[0] / dt, "h2d_bytes": int(h2d),
+            "d2h_bytes": ctx.width * ctx.height * ctx.bpp,
+            "includes": "H2D of the clip-space stream (+ varyings/colours) from pageable host memory, flush, D2H of the framebuffer"}
 
 
 def main():
@@ -65,10 +126,13 @@ def main():
     ap.add_argument("--writeout-frames", type=int, default=20,
                     help="clear-only frames timed after the run for the write-out figure (0 = skip, e.g. under rocprofv3 so "
                          "that the k_raster statistics hold the full launches only)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (profiling runs)")
+    ap.add_argument("--end-to-end-frames", type=int, default=2, help="PCIe-inclusive frames timed after the run (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL strip-gather path even with one rank (rehearsal)")
     ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3"],
                     help="c4 (default, the metric's config): 10 M random flat triangles; c2/c3: PHONG head stand-in at 2048/4096")
     args = ap.parse_args()
+    exit_code = [0]
 
     import torch
     from tinyrenderder_amd import scenes, shard
@@ -161,7 +225,8 @@ def main():
     phase_ms, nfl = ctx.phase_ms()
     info = ctx.last_flush_info()
     # frame write-out alone (outside the timed region): clear + flush with no triangles = k_raster storing W*H*(8+bpp)
-    # bytes once; BASELINE north_star's ">= 50 % of HBM roofline on framebuffer + z writes" is this figure
+    # bytes once, straight from the clear values.  It is the ceiling of the tile-out path, NOT what the C4 launch achieves
+    # on the same bytes (see "write_path" below).
     writeout = None
     if world == 1 and args.writeout_frames > 0:
         ctx.reset_phase_ms()
@@ -170,10 +235,45 @@ def main():
             ctx.flush()
         wo_ms, wo_n = ctx.phase_ms()
         wo_us = wo_ms[PHASE_RASTER_KERNEL] / max(wo_n, 1) * 1e3
-        writeout = {"bytes": W * H * 11, "kernel": "k_raster on a cleared frame without triangles", "avg_launch_us": wo_us,
+        writeout = {"kind": "clear-only", "bytes": W * H * 11, "kernel": "k_raster on a cleared frame without triangles", "avg_launch_us": wo_us,
                     "achieved": W * H * 11 / (wo_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": W * H * 11 / (wo_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
     ctx.set_profiling(False)
+
+    # ---- parity gate: no timing is reported unless the frame that was timed is the reference's ----
+    parity, cpu, e2e = {"checked": False, "ok": None}, None, None
+    golden_name = "c4_4096_10m" if (args.workload == "c4" and W == 4096 and N == 10_000_000) else None
+    if rank == 0 and world == 1 and not args.no_parity:
+        fb_timed = ctx.read_framebuffer()                      # the last timed frame
+        cpu_frame, checker, n_par = None, None, N
+        if args.workload == "c4" and args.cpu_sample > 0:
+            cpu, cpu_frame = cpu_baseline(clip, col, W, H, args.cpu_sample)
+            n_par = min(args.cpu_sample, N)
+            checker = ("the reference's own rasterize() (oracle/_ref/ref_harness_fast)" if cpu["kind"] == "reference"
+                       else "oracle/trgl_oracle.c (C restatement)")
+        elif args.workload != "c4" and args.cpu_sample > 0:    # PHONG stand-in frames: the C restatement is the only CPU checker
+            from oracle import orc
+            o = orc.Oracle(W, H, 3)
+            for slot, t in textures.items():
+                o.upload_texture(slot, t)
+            o.draw(orc.PHONG, clip, hd["varyings"], uniforms=orc.Uniforms.from_buffer_copy(bytes(uniforms)))
+            cpu_frame, checker = (o.fb, o.z, orc.format_stats_line(o.stats)), "oracle/trgl_oracle.c (C restatement; PHONG body restated from main.cpp text)"
+        parity, fb_par = parity_gate(ctx, kind, dclip, dvary, dcol, uniforms, n_par, cpu_frame, checker, golden_name)
+        if n_par == N:
+            parity["timed_frame_equals_parity_frame"] = bool(np.array_equal(fb_timed, fb_par))
+            if parity["checked"]:
+                parity["ok"] = bool(parity["ok"] and parity["timed_frame_equals_parity_frame"])
+        if args.end_to_end_frames > 0:
+            e2e = end_to_end(ctx, kind, clip, None if dvary is None else hd["varyings"], col, uniforms, args.end_to_end_frames)
+    elif rank == 0 and world > 1 and golden_name and not args.no_parity:
+        # multi-rank: rank 0 holds the gathered framebuffer (colour strips only travel); compare it with the reference's digest
+        import hashlib
+        gpath = os.path.join(ROOT, "tests", "golden", "golden_fullsize.json")
+        if os.path.exists(gpath):
+            g = json.load(open(gpath))[golden_name]
+            sha = hashlib.sha256(full_fb.cpu().numpy().tobytes()).hexdigest()
+            parity = {"checked": True, "ok": sha == g["fb"], "fb": sha == g["fb"], "z": None, "stats": None,
+                      "against": [f"tests/golden/golden_fullsize.json[{golden_name}] (gathered framebuffer on rank 0)"]}
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -183,20 +283,26 @@ def main():
         algo_bytes = (W * H * 11 + N * (96 + 8 * K)) / world
         raster_ms = phase_ms[PHASE_RASTER_KERNEL] / max(nfl, 1)       # the k_raster launch alone, HIP events on its stream
         achieved = algo_bytes / (raster_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, write_path = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if world == 1 and os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("workload") == f"c4_{W}x{H}_{N}":
                 traffic = tj.get("raster_hbm_bytes_per_launch")
+                # what the REAL launch does with the W*H*11 B that have to leave the chip (PMC WRITE_SIZE of k_raster)
+                write_path = {"kind": "full C4 launch", "write_size_bytes": tj["write_size_kib"] * 1024.0, "algorithmic_bytes": W * H * 11,
+                              "amplification": tj["write_size_kib"] * 1024.0 / (W * H * 11),
+                              "source": "profiles/traffic.json (rocprofv3 --pmc WRITE_SIZE of the same command, " + tj.get("round", "r01") + ")"}
+        failed = parity["checked"] and not parity["ok"]
         out = {
             "metric": "triangles/sec (+ Mpixels/sec) at 4096x4096; achieved HBM GB/s vs peak",
-            "value": tri_per_s, "unit": "triangles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": None if failed else tri_per_s, "unit": "triangles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl_name,
                        "width": W, "height": H, "triangles": N, "tile": 32,
                        "parallelism": f"screen strips x{world}" + (" + RCCL all-gather of colour strips" if world > 1 else "")},
+            "parity": parity,
             "mpixels_per_s": W * H * args.steps / elapsed / 1e6,
             "tri_tile_pairs": info["pairs"],
             "phase_ms": {"setup": phase_ms[PHASE_SETUP] / max(nfl, 1), "bin": phase_ms[PHASE_BIN] / max(nfl, 1),
@@ -221,12 +327,21 @@ def main():
                             "unit": "GB/s", "frac": bin_bytes / (bin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         if writeout:
             out["writeout"] = writeout
-        if world == 1 and args.cpu_sample > 0 and args.workload == "c4":
-            out["cpu_baseline"] = cpu_baseline(clip, col, W, H, args.cpu_sample)
+        if write_path:
+            out["write_path"] = write_path
+        if e2e:
+            out["end_to_end"] = e2e
+        if cpu:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
+        if failed:
+            print("PARITY FAILURE: the GPU frame differs from the reference's; no throughput is reported", file=sys.stderr)
+            exit_code[0] = 1
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+    if exit_code[0]:
+        sys.exit(exit_code[0])
 
 
 if __name__ == "__main__":

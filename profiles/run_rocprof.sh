@@ -8,7 +8,7 @@ OUT=gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --steps 3 --warmup 1 --cpu-sample 0 --writeout-frames 0"
+ARGS="bench.py --steps 3 --warmup 1 --cpu-sample 0 --writeout-frames 0 --no-parity --end-to-end-frames 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/bench_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/bench_pmc_write.log 2>&1

@@ -182,3 +182,20 @@ def run_gpu(case, strip=None, split=None):
         fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
         line = ctx.stats_line()
     return fb, z, st, line
+
+
+# ---- BASELINE configs[3] / [4] at their stated sizes (C4 = 10 M random triangles at 4096^2,
+# C5 = the C4-style scene at 8192^2, N = 10 M).  Too slow for the scalar oracle inside a test: the reference's own
+# rasterize() rendered them once (tests/golden/make_golden_fullsize.py) and tests/golden/golden_fullsize.json holds the
+# digests of its framebuffer bytes, z-buffer bits and its print_render_stats() line.
+def c4_4096_10m():
+    clip, col = scenes.random_triangles(10_000_000, 4096, 4096)          # = bench.py's default workload
+    return _case(4096, 4096, [(FLAT, None, clip, None, col)])
+
+
+def c5_8192_10m():
+    clip, col = scenes.random_triangles(10_000_000, 8192, 8192, seed=0x5EED0005, rmin=2, rmax=40)
+    return _case(8192, 8192, [(FLAT, None, clip, None, col)])
+
+
+FULLSIZE_CASES = {f.__name__: f for f in (c4_4096_10m, c5_8192_10m)}
