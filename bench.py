@@ -224,6 +224,7 @@ def main():
         elapsed = float(t.item())
     phase_ms, nfl = ctx.phase_ms()
     info = ctx.last_flush_info()
+    fb_timed = ctx.read_framebuffer() if (rank == 0 and world == 1 and not args.no_parity) else None     # the last timed frame
     # frame write-out alone (outside the timed region): clear + flush with no triangles = k_raster storing W*H*(8+bpp)
     # bytes once, straight from the clear values.  It is the ceiling of the tile-out path, NOT what the C4 launch achieves
     # on the same bytes (see "write_path" below).
@@ -244,7 +245,6 @@ def main():
     parity, cpu, e2e = {"checked": False, "ok": None}, None, None
     golden_name = "c4_4096_10m" if (args.workload == "c4" and W == 4096 and N == 10_000_000) else None
     if rank == 0 and world == 1 and not args.no_parity:
-        fb_timed = ctx.read_framebuffer()                      # the last timed frame
         cpu_frame, checker, n_par = None, None, N
         if args.workload == "c4" and args.cpu_sample > 0:
             cpu, cpu_frame = cpu_baseline(clip, col, W, H, args.cpu_sample)

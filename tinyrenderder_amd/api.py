@@ -80,11 +80,13 @@ class TrglError(RuntimeError):
 _lib = None
 
 
-def load_library(path: str = LIB_PATH):
-    """Load libtrgl.so and declare every prototype.  Raises if the library is absent."""
+def load_library(path: str = None):
+    """Load libtrgl.so and declare every prototype.  Raises if the library is absent.
+    TRGL_LIB in the environment names another build of the same library (profiles/: diagnostic and A/B builds)."""
     global _lib
     if _lib is not None:
         return _lib
+    path = path or os.environ.get("TRGL_LIB") or LIB_PATH
     # One HIP runtime per process: torch wheels bundle their own libamdhip64.  If libtrgl.so pulled in
     # /opt/rocm's copy first, a later `import torch` in the same process finds no GPUs; loaded after torch,
     # libtrgl.so binds to the runtime that is already there.  (A C/C++ host without torch is unaffected.)

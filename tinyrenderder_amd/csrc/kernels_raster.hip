@@ -19,6 +19,9 @@ namespace {
 
 __device__ __forceinline__ double dmax(double a, double b) { return (a < b) ? b : a; }   // std::max
 __device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; }   // std::min
+// v_max_f64 as one instruction (a NaN operand yields the other one): for the depth maxima, where a pixel holding NaN can
+// never be written again (z < NaN is false), so leaving it out of a maximum keeps the maximum a valid bound
+__device__ __forceinline__ double vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ int iclamp(int v, int lo, int hi) { return (v < lo) ? lo : (hi < v) ? hi : v; }
 __device__ __forceinline__ int x86_cvttsd2si(double d) {
     if (!(d > -2147483649.0 && d < 2147483648.0)) return INT_MIN;
@@ -228,13 +231,25 @@ __device__ __forceinline__ double div_by_uz(double a, double uz, double ruz) {
     return __builtin_fma(e1, ruz, q1);
 }
 
-// Per-triangle constants of the pixel loop (wave-uniform: they live in SGPRs).
+// Per-triangle constants of the pixel loop.  Every lane holds the same values: they come from ONE broadcast read of the
+// triangle's slot in LDS (all lanes read the same address), which costs 7 LDS instructions and no vector-ALU issue slot;
+// the 31 v_readlane that used to move them into SGPRs were 22 % of the kernel's VALU instructions (profiles/r01_raster_pmc.txt).
+// Only the three words that steer control flow are made wave-uniform (v_readfirstlane).
 struct TriConst {
     double ax, ay, s0x, s0y, s1x, s1y, uz, ruz, z0, z1, z2, iw0, iw1, iw2;
     double zbound;      // lower bound of the depth of any covered pixel (-inf if the triangle is not well scaled)
-    uint32_t rbox, color, dl;   // rbox: rx0 | ry0<<8 | (rx1-rx0)<<16 | (ry1-ry0)<<24, the clamped bbox relative to the tile origin
-    uint32_t blocks;    // bit k set: the k-th 8x8 block of the scan (row-major from the clamped bbox corner) may hold covered pixels
+    uint32_t color, dl, tri;    // per-lane copies
+    uint32_t rbox;      // SGPR: rx0 | ry0<<8 | (rx1-rx0)<<16 | (ry1-ry0)<<24, the clamped bbox relative to the tile origin
+    uint32_t blocks;    // SGPR: bit k set: the aligned 8x8 block k of the tile may hold covered pixels that pass the z-test
+    uint32_t j;         // SGPR: lane of the batch that holds this triangle's record (GOURAUD varyings ride in that lane)
 };
+// LDS slot of one surviving triangle of a batch: 16-byte chunks
+//   0: ax ay   1: s0x s0y   2: s1x s1y   3: uz ruz   4: z0 z1   5: z2 zbound   6: rbox, blocks | lane << 24, color, tri
+//   (kinds other than FLAT)  7: iw0 iw1   8: iw2, dl
+constexpr int TC_CHUNKS_FLAT = 7, TC_CHUNKS_ANY = 9;
+#ifndef TRGL_TC_BYTES
+#define TRGL_TC_BYTES 4480        // per wave: 40 FLAT slots (31 of the other kinds); with the 8.6 KB depth tile = 13.3 KB = 12 waves per CU
+#endif
 // Per-wave tile state.
 #ifdef TRGL_DEBUG_COUNTERS
 #define TRGL_DBG(i, n) (S.dbg[i] += (n))
@@ -265,7 +280,7 @@ constexpr int KIND_ANY = 4;
 struct VaryQ { uint4 v[2]; uint32_t color; };       // GOURAUD: three intensities + the base colour of lane j's triangle
 
 template <int KIND, bool WELL_SCALED>
-__device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& V, uint32_t tri_l, uint32_t j, TileState& S,
+__device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& V, TileState& S,
                                                 const DrawDesc* __restrict__ draws,
                                                 const DevTexture* __restrict__ tex, DevStats* __restrict__ stats) {
     constexpr bool FLAT_ONLY = KIND == TRGL_SHADER_FLAT;
@@ -361,16 +376,16 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                                 color = frag_gouraud(d.colors ? d.colors[local] : 0xffffffffu, d.vary + (size_t)local * d.K, pc);
                             } else {
                                 double vary[3];
-                                vary[0] = bcast_d(V.v[0].x, V.v[0].y, j); vary[1] = bcast_d(V.v[0].z, V.v[0].w, j);
-                                vary[2] = bcast_d(V.v[1].x, V.v[1].y, j);
-                                color = frag_gouraud(bcast_u(V.color, j), vary, pc);
+                                vary[0] = bcast_d(V.v[0].x, V.v[0].y, T.j); vary[1] = bcast_d(V.v[0].z, V.v[0].w, T.j);
+                                vary[2] = bcast_d(V.v[1].x, V.v[1].y, T.j);
+                                color = frag_gouraud(bcast_u(V.color, T.j), vary, pc);
                             }
                         } else {
                             shade_later = true;
                         }
                     }
                     if (KIND >= TRGL_SHADER_PHONG && S.id_lane)               // a flush with PHONG / EYE draws (wave-uniform)
-                        S.id_lane[(size_t)(8 * cy) * S.row_px + (size_t)(8 * cx)] = shade_later ? bcast_u(tri_l, j) : 0xffffffffu;
+                        S.id_lane[(size_t)(8 * cy) * S.row_px + (size_t)(8 * cx)] = shade_later ? T.tri : 0xffffffffu;
 #ifdef TRGL_DEBUG_COUNTERS
                     if (dropped) TRGL_DBG(7, 1);                              // must stay 0
 #endif
@@ -389,7 +404,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                         S.zmin = dmin(S.zmin, z); S.zmax = dmax(S.zmax, z);
                         if (z == 0.0 && !S.zero_locked) {
                             const int x = bx + (S.lane & 7), y = by + (S.lane >> 3);
-                            unsigned long long order = ((unsigned long long)bcast_u(tri_l, j) << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
+                            unsigned long long order = ((unsigned long long)T.tri << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
                             atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
                         }
                     }
@@ -460,7 +475,7 @@ __device__ __forceinline__ void tile_clear_color(const FrameParams& fp, int lane
 }
 
 template <int KIND>
-__global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
+__global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
                                                 const uint32_t* __restrict__ tile_start,
                                                 const uint32_t* __restrict__ tile_end,
@@ -470,6 +485,7 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
                                                 unsigned long long* __restrict__ item_stats) {
     __shared__ __attribute__((aligned(16))) double   s_z[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
     __shared__ double s_hz[TRGL_WAVES_PER_BLOCK][80];    // depth maxima of the 64 4x4-pixel cells + 16 8x8-pixel cells
+    __shared__ __attribute__((aligned(16))) uint4 s_tc[TRGL_WAVES_PER_BLOCK][TRGL_TC_BYTES / 16];   // scan constants of a batch's surviving triangles
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -522,13 +538,18 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
             if (x <= xa1 && y >= ya0 && y <= ya1) fp.idbuf[(size_t)x + (size_t)y * fp.W] = 0xffffffffu;
         }
     }
+    // Pixels of the tile that this item does not own (other bands, rows outside the strip, beyond the image) hold -inf: they
+    // are never scanned or stored, and the depth-maxima reduction of the batch phase needs no ownership masks.
     if (fp.init_from_clear) {
-        for (int k = lane; k < TRGL_TILE_PIX; k += 64) zt[k] = fp.clear_z;
+        for (int r = 0; r < TRGL_TILE; r += 2) {
+            const int x = px0 + (lane & 31), y = py0 + r + (lane >> 5);
+            zt[lds_index(x, y)] = (x <= xa1 && y >= ya0 && y <= ya1) ? fp.clear_z : -__builtin_inf();
+        }
         tile_clear_color(fp, lane, px0, py0, xa1, ya0, ya1);
     } else {
         for (int r = 0; r < TRGL_TILE; r += 2) {
             int x = px0 + (lane & 31), y = py0 + r + (lane >> 5);
-            double z = fp.clear_z;
+            double z = -__builtin_inf();
             if (x <= xa1 && y >= ya0 && y <= ya1) z = fp.zb[(size_t)x + (size_t)y * fp.W];
             zt[lds_index(x, y)] = z;
         }
@@ -573,6 +594,7 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
         for (int k = 0; k < 8; ++k) cur.q[k] = make_uint4(0, 0, 0, 0);
     }
     double* hz = s_hz[w];
+    uint4* tc = s_tc[w];
     VaryQ V;
     V.color = 0; V.v[0] = make_uint4(0, 0, 0, 0); V.v[1] = make_uint4(0, 0, 0, 0);
     for (uint32_t bs = beg; bs < end; bs += 64) {
@@ -609,18 +631,14 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
             double m = -__builtin_inf();
 #pragma unroll
             for (int dy = 0; dy < 4; ++dy) {
-                const bool row_owned = (py0 + 4 * cy + dy >= ya0) && (py0 + 4 * cy + dy <= ya1) && (px0 + 4 * cx <= xa1);
 #pragma unroll
-                for (int dx = 0; dx < 4; ++dx) {
-                    const double v = zt[lds_index(4 * cx + dx, 4 * cy + dy)];
-                    m = dmax(m, row_owned ? v : -__builtin_inf());
-                }
+                for (int dx = 0; dx < 4; ++dx) m = vmax(m, zt[lds_index(4 * cx + dx, 4 * cy + dy)]);
             }
             hz[lane] = m;
             __builtin_amdgcn_wave_barrier();
             if (lane < 16) {
                 const int f = (lane >> 2) * 16 + (lane & 3) * 2;
-                hz[64 + lane] = dmax(dmax(hz[f], hz[f + 1]), dmax(hz[f + 8], hz[f + 9]));
+                hz[64 + lane] = vmax(vmax(hz[f], hz[f + 1]), vmax(hz[f + 8], hz[f + 9]));
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -688,6 +706,7 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
                     blocks_l = mk;
                 }
                 skip = blocks_l == 0;
+                if (ruz_l != 0.0) blocks_l |= 0x10000u;       // bit 16: well scaled (selects the division-free scan)
             }
             todo = __ballot(!skip);
             if (HAS_V && !skip) {        // this lane's triangle will be rasterized: fetch its varyings now
@@ -701,26 +720,55 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
                 V.color = d.colors ? d.colors[local] : 0xffffffffu;
             }
         }
+        // ---- the surviving triangles, in list order (= ascending lane): constants to LDS, then one broadcast read each ----
+        // The survivors of the batch (57 % of its entries on C4) write their scan constants into consecutive 112-byte slots
+        // of the wave's LDS area; a slot is read back by ALL lanes at the same address.  When there are more survivors than
+        // slots the batch is served in rounds.
+        constexpr int CH = FLAT_ONLY ? TC_CHUNKS_FLAT : TC_CHUNKS_ANY;
+        constexpr uint32_t SLOTS = TRGL_TC_BYTES / (16 * CH);
+        const unsigned long long lanes_below = (1ull << lane) - 1ull;
         while (todo) {
-            const uint32_t j = (uint32_t)__builtin_ctzll(todo);          // list order = ascending lane
-            todo &= todo - 1;
-            TriConst T;
-            T.ax = bcast_d(cur.q[0].x, cur.q[0].y, j); T.ay = bcast_d(cur.q[0].z, cur.q[0].w, j);
-            T.s0x = bcast_d(cur.q[1].x, cur.q[1].y, j); T.s0y = bcast_d(cur.q[1].z, cur.q[1].w, j);
-            T.s1x = bcast_d(cur.q[2].x, cur.q[2].y, j); T.s1y = bcast_d(cur.q[2].z, cur.q[2].w, j);
-            T.uz = bcast_d(cur.q[3].x, cur.q[3].y, j); T.ruz = bcast_d(cur.q[3].z, cur.q[3].w, j);
-            T.z0 = bcast_d(cur.q[4].x, cur.q[4].y, j); T.z1 = bcast_d(cur.q[4].z, cur.q[4].w, j);
-            T.z2 = bcast_d(cur.q[5].x, cur.q[5].y, j);
-            if (!FLAT_ONLY) {
-                T.iw0 = bcast_d(cur.q[5].z, cur.q[5].w, j); T.iw1 = bcast_d(cur.q[6].x, cur.q[6].y, j);
-                T.iw2 = bcast_d(cur.q[6].z, cur.q[6].w, j); T.dl = bcast_u(cur.q[7].w, j);
+            const uint32_t rank = (uint32_t)__popcll(todo & lanes_below);
+            const bool mine = ((todo >> lane) & 1ull) && rank < SLOTS;
+            if (mine) {
+                uint4* d = tc + rank * CH;
+                d[0] = cur.q[0]; d[1] = cur.q[1]; d[2] = cur.q[2]; d[3] = cur.q[3]; d[4] = cur.q[4];
+                d[5] = make_uint4(cur.q[5].x, cur.q[5].y, (uint32_t)__double2loint(zbound_l), (uint32_t)__double2hiint(zbound_l));
+                d[6] = make_uint4(rbox_l, blocks_l | ((uint32_t)lane << 24), cur.q[7].z, cur.tri);
+                if (!FLAT_ONLY) {
+                    d[7] = make_uint4(cur.q[5].z, cur.q[5].w, cur.q[6].x, cur.q[6].y);
+                    d[8] = make_uint4(cur.q[6].z, cur.q[6].w, cur.q[7].w, 0u);
+                }
             }
-            T.rbox = bcast_u(rbox_l, j); T.color = bcast_u(cur.q[7].z, j);
-            T.blocks = bcast_u(blocks_l, j);
-            T.zbound = bcast_d((uint32_t)__double2loint(zbound_l), (uint32_t)__double2hiint(zbound_l), j);
-            TRGL_DBG(0, 1);                                                    // list entries rasterized (not skipped)
-            if (T.ruz != 0.0) raster_triangle<KIND, true>(T, V, cur.tri, j, S, draws, tex, stats);    // wave-uniform
-            else raster_triangle<KIND, false>(T, V, cur.tri, j, S, draws, tex, stats);
+            const unsigned long long round = __ballot(mine);
+            todo &= ~round;
+            const uint32_t n_round = (uint32_t)__popcll(round);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t sl = 0; sl < n_round; ++sl) {
+                const uint4* p = tc + sl * CH;                                  // the same address in every lane
+                const double2* pd = reinterpret_cast<const double2*>(p);
+                const double2 d0 = pd[0], d1 = pd[1], d2 = pd[2], d3 = pd[3], d4 = pd[4], d5 = pd[5];
+                const uint4 c6 = p[6];
+                TriConst T;
+                T.ax = d0.x; T.ay = d0.y; T.s0x = d1.x; T.s0y = d1.y; T.s1x = d2.x; T.s1y = d2.y;
+                T.uz = d3.x; T.ruz = d3.y; T.z0 = d4.x; T.z1 = d4.y; T.z2 = d5.x; T.zbound = d5.y;
+                T.rbox = (uint32_t)__builtin_amdgcn_readfirstlane((int)c6.x);
+                const uint32_t bw = (uint32_t)__builtin_amdgcn_readfirstlane((int)c6.y);
+                T.blocks = bw & 0xffffu; T.j = bw >> 24;
+                T.color = c6.z; T.tri = c6.w;
+                T.iw0 = T.iw1 = T.iw2 = 0.0; T.dl = 0;
+                if (!FLAT_ONLY) {
+                    const double2 d7 = pd[7];
+                    const uint4 c8 = p[8];
+                    T.iw0 = d7.x; T.iw1 = d7.y; T.iw2 = __hiloint2double((int)c8.y, (int)c8.x);
+                    T.dl = (uint32_t)__builtin_amdgcn_readfirstlane((int)c8.z);
+                }
+                TRGL_DBG(0, 1);                                                    // list entries rasterized (not skipped)
+                // "well scaled" is a property of the triangle (k_setup leaves ruz = 0 otherwise): wave-uniform by construction
+                if (bw & 0x10000u) raster_triangle<KIND, true>(T, V, S, draws, tex, stats);
+                else raster_triangle<KIND, false>(T, V, S, draws, tex, stats);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         if (PREFETCH) cur = nxt;
         else if (bs + 64 < end) {
