@@ -12,5 +12,6 @@ L.trgl_draw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
 assert L.trgl_draw(h, 0, None, dclip.data_ptr(), None, dcol.data_ptr(), N, 1) == 0
 out = (C.c_ulonglong * 8)(); L.trgl_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
 assert L.trgl_debug_counters(h, out) == 0
-names = ["entries rasterized", "blocks in coverage test", "blocks with coverage", "blocks reaching divisions", "list entries (pairs)", "blocks with no z-alive lane", "blocks dropped by the per-lane edge mask", "... of which had coverage (must be 0)"]
-for n, v in zip(names, out): print(f"{n:28s} {v:>12d}  per triangle {v / N:.3f}")
+names = ["triangles scanned (slots read)", "blocks visited", "blocks reaching the divisions", "lanes that could still win (z-alive)", "list entries (pairs)",
+         "visited blocks with no z-alive lane", "blocks dropped by the per-lane masks", "... of which wrote a pixel (must be 0)"]
+for n, v in zip(names, out): print(f"{n:44s} {v:>12d}  per triangle {v / N:.3f}")

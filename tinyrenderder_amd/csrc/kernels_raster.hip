@@ -248,7 +248,7 @@ struct TriConst {
 //   (kinds other than FLAT)  7: iw0 iw1   8: iw2, dl
 constexpr int TC_CHUNKS_FLAT = 7, TC_CHUNKS_ANY = 9;
 #ifndef TRGL_TC_BYTES
-#define TRGL_TC_BYTES 4480        // per wave: 40 FLAT slots (31 of the other kinds); with the 8.6 KB depth tile = 13.3 KB = 12 waves per CU
+#define TRGL_TC_BYTES 1456        // per wave: 13 FLAT slots (10 of the other kinds); with the 8.5 KB depth tile = 10 KB = 16 waves per CU
 #endif
 // Per-wave tile state.
 #ifdef TRGL_DEBUG_COUNTERS
@@ -311,40 +311,45 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
             const bool act = (uint32_t)((S.lane & 7) + (8 * cx - rx0)) <= (uint32_t)(rx1 - rx0) &&
                              (uint32_t)((S.lane >> 3) + (8 * cy - ry0)) <= (uint32_t)(ry1 - ry0);
             const int bx = S.px0 + 8 * cx, by = S.py0 + 8 * cy;
-            TRGL_DBG(1, 1);                                                    // blocks entering the coverage test
 #ifdef TRGL_DEBUG_COUNTERS
-            if (WELL_SCALED && __ballot(act && T.zbound < S.zt[(256 * cy + S.lrow) + ((8 * cx) ^ S.lsw)]) == 0) TRGL_DBG(5, 1);   // no lane of the block could pass
+            if (!dropped) TRGL_DBG(1, 1);                                      // blocks visited (the diagnostic build also walks the dropped ones)
 #endif
-            // pixel centre (x+0.5, y+0.5), our_gl.cpp:149: (2^51 + bx) + (lx + 0.5 - 2^51) is exact
-            const double pxc = __hiloint2double(0x43200000, bx << 1) + S.lxm;
-            const double pyc = __hiloint2double(0x43200000, by << 1) + S.lym;
-            // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
-            const double s0z = T.ax - pxc, s1z = T.ay - pyc;
-            const double ux = T.s0y * s1z - s0z * T.s1y;                      // geometry.h:145
-            const double uy = s0z * T.s1x - T.s0x * s1z;                      // geometry.h:146
-            const double us = ux + uy;
-            double b0, b1, b2;
-            bool cov;
-            if (WELL_SCALED) {
-                // u.z < 0 and nothing can over/underflow, so the signs of the quotients are known
-                // without dividing: u.y/u.z < 0 <=> u.y > 0, u.x/u.z < 0 <=> u.x > 0, and
-                // 1 - RN(us/u.z) < 0 <=> RN(us/u.z) > 1 <=> us < u.z  ("exactness").
-                cov = act && !(us < uz) && !(uy > 0.0) && !(ux > 0.0);        // :152
-            } else {
-                b0 = 1.0 - us / uz;                                           // :85, as written
-                b1 = uy / uz;
-                b2 = ux / uz;
-                cov = act && !(b0 < 0 || b1 < 0 || b2 < 0);                   // :152
-            }
-            if (__ballot(cov)) TRGL_DBG(2, 1);                                 // blocks with coverage
-            if (cov) {
-                const int li = (256 * cy + S.lrow) + ((8 * cx) ^ S.lsw);   // = lds_index(x, y) for an aligned block
-                const double zold = S.zt[li];
-                if (__ballot(!WELL_SCALED || T.zbound < zold)) TRGL_DBG(3, 1); // blocks that reach the divisions
-                // early z, exact: every covered pixel of this triangle has z >= T.zbound (see the block-mask
-                // comment in k_raster) and the test is a strict `<`, so a pixel with zbound >= zold cannot pass;
-                // when no covered lane is left the whole division / depth phase is skipped
-                if (!WELL_SCALED || T.zbound < zold) {
+            // Stored depth first: every covered pixel of this triangle has z >= T.zbound (see the block-mask comment in
+            // k_raster; -inf for a triangle that is not well scaled) and the z-test is a strict `<`, so a pixel with
+            // zbound >= zold (or zold = NaN) cannot be written whatever its coverage: only lanes that can still win run the
+            // coverage arithmetic, and a block without such a lane costs 8 vector instructions instead of 18.
+            const int li = (256 * cy + S.lrow) + ((8 * cx) ^ S.lsw);           // = lds_index(x, y) for an aligned block
+            const double zold = S.zt[li];
+            const bool alive = act && (T.zbound < zold);
+#ifdef TRGL_DEBUG_COUNTERS
+            if (!dropped) { if (__ballot(alive) == 0) TRGL_DBG(5, 1); TRGL_DBG(3, __popcll(__ballot(alive))); }   // blocks without a lane that could pass; such lanes
+#endif
+            if (alive) {
+                // pixel centre (x+0.5, y+0.5), our_gl.cpp:149: (2^51 + bx) + (lx + 0.5 - 2^51) is exact
+                const double pxc = __hiloint2double(0x43200000, bx << 1) + S.lxm;
+                const double pyc = __hiloint2double(0x43200000, by << 1) + S.lym;
+                // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
+                const double s0z = T.ax - pxc, s1z = T.ay - pyc;
+                const double ux = T.s0y * s1z - s0z * T.s1y;                      // geometry.h:145
+                const double uy = s0z * T.s1x - T.s0x * s1z;                      // geometry.h:146
+                const double us = ux + uy;
+                double b0, b1, b2;
+                bool cov;
+                if (WELL_SCALED) {
+                    // u.z < 0 and nothing can over/underflow, so the signs of the quotients are known
+                    // without dividing: u.y/u.z < 0 <=> u.y > 0, u.x/u.z < 0 <=> u.x > 0, and
+                    // 1 - RN(us/u.z) < 0 <=> RN(us/u.z) > 1 <=> us < u.z  ("exactness").
+                    cov = !(us < uz) && !(uy > 0.0) && !(ux > 0.0);               // :152
+                } else {
+                    b0 = 1.0 - us / uz;                                           // :85, as written
+                    b1 = uy / uz;
+                    b2 = ux / uz;
+                    cov = !(b0 < 0 || b1 < 0 || b2 < 0);                          // :152
+                }
+#ifdef TRGL_DEBUG_COUNTERS
+                if (!dropped && __ballot(cov)) TRGL_DBG(2, 1);                     // blocks that reach the divisions
+#endif
+                if (cov) {
                 if (WELL_SCALED) {
                     b0 = 1.0 - div_by_uz(us, uz, ruz);
                     b1 = div_by_uz(uy, uz, ruz);
@@ -475,7 +480,7 @@ __device__ __forceinline__ void tile_clear_color(const FrameParams& fp, int lane
 }
 
 template <int KIND>
-__global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
+__global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu((KIND == TRGL_SHADER_GOURAUD || KIND == 4) ? 3 : 4, 4))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
                                                 const uint32_t* __restrict__ tile_start,
                                                 const uint32_t* __restrict__ tile_end,
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
                                                 const uint32_t* __restrict__ items, const uint32_t* __restrict__ n_items,
                                                 unsigned long long* __restrict__ item_stats) {
     __shared__ __attribute__((aligned(16))) double   s_z[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
-    __shared__ double s_hz[TRGL_WAVES_PER_BLOCK][80];    // depth maxima of the 64 4x4-pixel cells + 16 8x8-pixel cells
+    __shared__ double s_hz[TRGL_WAVES_PER_BLOCK][64];    // depth maxima of the 64 4x4-pixel cells of the tile
     __shared__ __attribute__((aligned(16))) uint4 s_tc[TRGL_WAVES_PER_BLOCK][TRGL_TC_BYTES / 16];   // scan constants of a batch's surviving triangles
 
     const int lane = threadIdx.x & 63;
@@ -636,11 +641,6 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
             }
             hz[lane] = m;
             __builtin_amdgcn_wave_barrier();
-            if (lane < 16) {
-                const int f = (lane >> 2) * 16 + (lane & 3) * 2;
-                hz[64 + lane] = vmax(vmax(hz[f], hz[f + 1]), vmax(hz[f + 8], hz[f + 9]));
-            }
-            __builtin_amdgcn_wave_barrier();
         }
         unsigned long long todo;
         double zbound_l = -__builtin_inf();       // this lane's triangle: lower bound of its covered depths
@@ -655,6 +655,7 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
             if (!skip) {
                 rbox_l = (uint32_t)(x0 - px0) | ((uint32_t)(y0 - py0) << 8) | ((uint32_t)(x1 - x0) << 16) | ((uint32_t)(y1 - y0) << 24);
                 const int c0 = (x0 - px0) >> 3, c1 = (x1 - px0) >> 3, r0 = (y0 - py0) >> 3, r1 = (y1 - py0) >> 3;
+                const int cc0 = (x0 - px0) >> 2, cc1 = (x1 - px0) >> 2, cr0 = (y0 - py0) >> 2, cr1 = (y1 - py0) >> 2;   // in 4x4 cells
                 if (ruz_l == 0.0) {                // not well scaled: the literal path scans every block of the bbox
                     blocks_l = (((2u << c1) - (1u << c0)) & 0xfu) * 0x1111u & ((0xffffu >> (12 - 4 * r1)) & (0xffffu << (4 * r0)));
                 } else {
@@ -694,8 +695,13 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
                     uint32_t mk = 0;
                     for (int r = r0; r <= r1; ++r) {
                         double fa = fa_row, fb = fb_row, fc = fc_row, fz = fz_row;
+                        // the cell rows of block row r that the clamped bbox reaches (the same row twice if only one)
+                        const int ra = 8 * max(2 * r, cr0), rb = 8 * min(2 * r + 1, cr1);
                         for (int c = c0; c <= c1; ++c) {
-                            const double top = hz[64 + 4 * r + c];
+                            // stored maximum over the 4x4 cells of the block that hold pixels of the clamped bbox: no other
+                            // pixel of the block is scanned for this triangle
+                            const int ca = max(2 * c, cc0), cb = min(2 * c + 1, cc1);
+                            const double top = vmax(vmax(hz[ra + ca], hz[ra + cb]), vmax(hz[rb + ca], hz[rb + cb]));
                             const bool outside = fa > ma || fb > mb || fc < lim_c;
                             const bool behind = fz >= top || zbound >= top;
                             if (!(outside || behind)) mk |= 1u << (4 * r + c);
