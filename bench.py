@@ -26,13 +26,6 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
 
-class _DevBuf:
-    """Expose a raw device pointer to torch through __cuda_array_interface__."""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
-
-
 def cpu_baseline(clip, col, W, H, sample):
     """Single-thread CPU rate on a bounded prefix of the same workload: the reference's own rasterize()
     (oracle/_ref, built -O3 -DNDEBUG -ffp-contract=off) when it travelled to this box, else the C restatement.
@@ -182,29 +175,27 @@ def main():
     full_fb = None
     if use_dist:
         ctx.set_strip(y0, y1)
-        full_fb = torch.as_tensor(_DevBuf(ctx.framebuffer_ptr, W * H * 3), device="cuda")
+        full_fb = shard.framebuffer_tensor(ctx)
 
-    gather = [None]      # the RCCL all-gather of the previous frame's strips, still in flight
+    def submit(c):
+        c.clear()
+        c.draw(kind, dclip, varyings=dvary, colors=dcol, uniforms=uniforms, device=True)
+
+    # N > 1: join the colour strips so that every rank ends with the whole TGAImage buffer.  The gather runs on RCCL's stream;
+    # only the raster half of the NEXT frame touches the framebuffer, so that frame's setup and binning run under it
+    # (shard.StripLoop; tests/test_gpu_parity.py drives the same loop with two contexts on one GPU).
+    loop = shard.StripLoop(ctx, lambda: shard.gather_strips(full_fb, W, H, 3, rank, world, async_op=True)) if use_dist else None
 
     def step():
-        ctx.clear()
-        ctx.draw(kind, dclip, varyings=dvary, colors=dcol, uniforms=uniforms, device=True)
-        if not use_dist:
+        if loop is None:
+            submit(ctx)
             ctx.flush()
-            return
-        # Join the colour strips: every rank ends with the whole TGAImage buffer.  The gather runs on RCCL's stream;
-        # only the raster half of the NEXT frame touches the framebuffer, so that frame's setup and binning run under it.
-        ctx.flush_begin()
-        if gather[0] is not None:
-            gather[0].wait()                     # this stream waits for the gather before the raster overwrites the strip
-        ctx.flush_end()
-        gather[0] = shard.gather_strips(full_fb, W, H, 3, rank, world, async_op=True)
+        else:
+            loop.step(submit)
 
     def fence():
         if use_dist:
-            if gather[0] is not None:
-                gather[0].wait()
-                gather[0] = None
+            loop.finish()
             dist.barrier()
         torch.cuda.synchronize()
 

@@ -52,6 +52,12 @@ extern "C" {
  *   EYE     : EyeShader::fragment   (main.cpp:220-261), K=24 doubles per triangle.
  * Varyings layout for PHONG/EYE is the memory image of the shader's three member arrays
  * (main.cpp:47-49,181-183): uv[3] (6 doubles), position_eye[3] (9), normal_eye[3] (9).
+ *
+ * Contract: no device kind ever discards.  rasterize() skips the depth and colour write when fragment() returns
+ * {true, ...} (our_gl.cpp:187-188); both shaders the reference ships always return false (main.cpp:169,260), and so do the
+ * four kinds above.  The PHONG/EYE path relies on it: with no discard and no side effects in fragment(), shading only the
+ * last fragment that passed the z-test at a pixel gives the framebuffer of shading every z-pass in order.  A shader that
+ * discards needs its own kind with in-order shading; it cannot be expressed through this interface today.
  */
 #define TRGL_SHADER_FLAT    0
 #define TRGL_SHADER_GOURAUD 1

@@ -420,3 +420,178 @@ def test_fuzz_flat_scenes_against_oracle(seed):
     assert np.array_equal(z[rows].view(np.uint64), o.z[rows].view(np.uint64))
     assert np.array_equal(fb[rows], o.fb[rows])
     assert st == o.stats
+
+
+def test_mixed_flush_with_gouraud_runs_the_any_kernel():
+    """One flush holding GOURAUD, PHONG, FLAT and EYE draws: k_raster<ANY> serves it, and its GOURAUD branch reads the
+    varyings and base colours through the draw descriptor (d.vary + local * K), not from the batch registers."""
+    from tinyrenderder_amd.api import GOURAUD, PHONG, EYE, make_uniforms
+    w, h = 288, 176
+    hd = scenes.head_standin(3, w, h)
+    d, n, sp = scenes.procedural_textures(64)
+    u = make_uniforms(hd["model_view"], hd["key"], hd["fill"], hd["rim"], 1.0, 0, 1, 2)
+    gclip, gcol = scenes.random_triangles(3000, w, h, seed=71, rmin=2, rmax=48, perspective_w=True)
+    ginten = scenes.SplitMix64(72).uniform(3000 * 3, -0.2, 1.3).reshape(3000, 3)
+    fclip, fcol = scenes.random_triangles(800, w, h, seed=73, rmin=2, rmax=24)
+    small = scenes.head_standin(2, w, h, seed=5, distance=4.0)
+    case = cases._case(w, h, [(GOURAUD, None, gclip[:1500], ginten[:1500], gcol[:1500]), (PHONG, u, hd["clip"], hd["varyings"], None),
+                              (GOURAUD, None, gclip[1500:], ginten[1500:], gcol[1500:]), (FLAT, None, fclip, None, fcol),
+                              (EYE, u, small["clip"], small["varyings"], None)],
+                       textures={0: d, 1: n, 2: sp}, clear=(3, 2, 1, 255))
+    ofb, oz, ost = cases.run_oracle(case)
+    for bpp in (3,):
+        fb, z, st, _ = cases.run_gpu(case)
+        assert np.array_equal(z.view(np.uint64), oz.view(np.uint64)) and st == ost
+        diff = np.abs(fb.astype(np.int16) - ofb.astype(np.int16))           # EYE: pow(x, 8), at most 1 LSB on at most 0.1 % of the bytes
+        assert diff.max() <= 1 and (diff != 0).mean() <= 1e-3
+    # the same frame without the EYE draw is byte-exact
+    case["draws"] = case["draws"][:4]
+    ofb, oz, ost = cases.run_oracle(case)
+    fb, z, st, _ = cases.run_gpu(case)
+    assert np.array_equal(fb, ofb) and np.array_equal(z.view(np.uint64), oz.view(np.uint64)) and st == ost
+
+
+def test_more_draws_than_descriptors_between_flushes():
+    """70 small trgl_draw calls from host memory without a flush in between: the 65th finds the 64 draw descriptors of a
+    flush taken and flushes on its own (trgl_api.cpp, trgl_draw), while the staged host arrays of the draw in progress stay
+    alive.  The frame equals the oracle's, which sees one rasterize() loop."""
+    W, H = 200, 120
+    clip, col = scenes.random_triangles(70 * 37, W, H, seed=81, rmin=2, rmax=30, perspective_w=True)
+    with Context(W, H, 3) as ctx:
+        for i in range(70):
+            ctx.draw(FLAT, clip[37 * i: 37 * (i + 1)], colors=col[37 * i: 37 * (i + 1)])
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    o = orc.Oracle(W, H, 3)
+    o.draw(orc.FLAT, clip, colors=col)
+    assert np.array_equal(fb, o.fb) and np.array_equal(z.view(np.uint64), o.z.view(np.uint64)) and st == o.stats
+
+
+def test_one_draw_of_more_than_2_to_24_triangles():
+    """A record addresses its triangle as (draw, 24-bit index), so trgl_draw splits a submission of 2^24 + 40 000 triangles into
+    two descriptors whose clip / colour pointers are offset.  The last 40 000 triangles (the second descriptor) are the
+    visible ones: wrong offsets would show as wrong colours or positions.  Host arrays (1.6 GB of clip data)."""
+    W, H = 256, 256
+    n_small, n_vis = (1 << 24) + 3000, 37_000
+    vis, vcol = scenes.random_triangles(n_vis + 3000, W, H, seed=91, rmin=2, rmax=30)
+    clip = np.empty((n_small + n_vis, 12))
+    col = (np.arange(n_small + n_vis, dtype=np.uint64) * np.uint64(2654435761) & np.uint64(0xFFFFFF)).astype(np.uint32) | np.uint32(0xFF000000)
+    # the first 2^24 + 3000 triangles are the first 3000 of `vis` shrunk around their first vertex to 1/1000 of a pixel (almost never
+    # cover a pixel centre, cheap for the oracle) and repeated; the rest are ordinary
+    base = vis[:3000].copy()
+    for v in (1, 2):
+        base[:, 4 * v: 4 * v + 2] = base[:, 0:2] + (base[:, 4 * v: 4 * v + 2] - base[:, 0:2]) * 1e-3
+    reps = -(-n_small // 3000)
+    clip[:n_small] = np.tile(base, (reps, 1))[:n_small]
+    clip[n_small:] = vis[3000:]
+    with Context(W, H, 3) as ctx:
+        ctx.draw(FLAT, clip, colors=col)
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    o = orc.Oracle(W, H, 3)
+    o.draw(orc.FLAT, clip, colors=col)
+    assert st == o.stats and st[0] == n_small + n_vis
+    assert np.array_equal(fb, o.fb) and np.array_equal(z.view(np.uint64), o.z.view(np.uint64))
+
+
+def test_pair_buffers_grow_behind_an_optimistic_launch():
+    """The binning kernels are queued for the capacity the pair buffers already have (first flush: 2 pairs per triangle) and do
+    nothing when the flush needs more; trgl_flush_end then grows the buffers and queues them again.  100 full-screen triangles
+    at 512x512 are 25 600 pairs against a first guess of 4 296; a second, larger frame grows them once more."""
+    W = H = 512
+    clip, col = scenes.random_triangles(100, W, H, seed=95, rmin=600, rmax=1200)
+    big, bcol = scenes.random_triangles(300, W, H, seed=96, rmin=600, rmax=1200)
+    with Context(W, H, 3) as ctx:
+        ctx.draw(FLAT, clip, colors=col)
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+        assert ctx.last_flush_info()["pairs"] > 2 * 100 + 4096
+        o = orc.Oracle(W, H, 3)
+        o.draw(orc.FLAT, clip, colors=col)
+        assert np.array_equal(fb, o.fb) and np.array_equal(z.view(np.uint64), o.z.view(np.uint64)) and st == o.stats
+        ctx.draw(FLAT, big, colors=bcol)
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+        o.draw(orc.FLAT, big, colors=bcol)
+        assert np.array_equal(fb, o.fb) and np.array_equal(z.view(np.uint64), o.z.view(np.uint64)) and st == o.stats
+
+
+def test_more_than_2_to_32_pairs_is_refused_not_wrapped():
+    """70 000 full-screen triangles at 8192x8192 are 4.6e9 (tile, triangle) pairs: the pair count is accumulated in 64 bits
+    on the device (k_chunk_spine), every binning kernel sees it exceed the buffers and does nothing, and the flush returns
+    TRGL_E_UNSUPPORTED instead of drawing from wrapped offsets.  The context stays usable."""
+    from tinyrenderder_amd.api import TrglError
+    W = H = 8192
+    n = 70_000
+    clip = np.empty((n, 12))
+    clip[:] = [-3.0, -3.0, 0.0, 1.0, 3.0, -3.0, 0.0, 1.0, 0.0, 3.0, 0.0, 1.0]      # covers the whole screen, counter-clockwise
+    col = np.full(n, 0xFF00FF00, np.uint32)
+    with Context(W, H, 3) as ctx:
+        ctx.draw(FLAT, clip, colors=col)
+        with pytest.raises(TrglError):
+            ctx.flush()
+        small, scol = scenes.random_triangles(2000, W, H, seed=97, rmin=4, rmax=40)
+        ctx.clear()
+        ctx.draw(FLAT, small, colors=scol)
+        fb = ctx.read_framebuffer()
+    o = orc.Oracle(W, H, 3)
+    o.draw(orc.FLAT, small, colors=scol)
+    assert np.array_equal(fb, o.fb)
+
+
+def test_strip_loop_two_contexts_interleaved_frames():
+    """bench.py's N > 1 frame loop (shard.StripLoop: submit -> flush_begin -> wait for the previous gather -> flush_end -> start
+    the gather, in place into an alias of the context's own framebuffer) driven by TWO strip contexts on one GPU over three
+    different frames.  The collective is replaced by what it does to one rank's memory: the peer's strip lands in place, and
+    it lands late - while the next frame's setup and binning are already queued - exactly when StripLoop waits for it.
+    Checked after every frame: the rank's own rows hold the new frame, the rows it does not own still hold the peer's
+    PREVIOUS frame (a pending clear must not touch them), and after the last gather both ranks hold the whole last frame."""
+    import torch
+    from tinyrenderder_amd import shard
+    W, H, cut = 256, 192, 96
+    frames = [scenes.random_triangles(6000, W, H, seed=300 + k, rmin=2, rmax=40, perspective_w=bool(k & 1)) for k in range(3)]
+    want = []
+    for clip, col in frames:
+        o = orc.Oracle(W, H, 3, clear_bgra=(5 * len(want) + 1, 2, 3, 255))
+        o.draw(orc.FLAT, clip, colors=col)
+        want.append(o.fb.copy())
+    stream = torch.cuda.current_stream().cuda_stream
+    ctxs = [Context(W, H, 3), Context(W, H, 3)]
+    rows = [(0, cut), (cut, H)]
+    full = []
+    for c, (y0, y1) in zip(ctxs, rows):
+        c.set_stream(stream)
+        c.set_strip(y0, y1)
+        full.append(shard.framebuffer_tensor(c))
+
+    class LateCopy:                       # the peer's strip, joined in place when the loop waits for the gather
+        def __init__(self, me):
+            self.me = me
+
+        def wait(self):
+            y0, y1 = rows[1 - self.me]
+            full[self.me][y0 * W * 3: y1 * W * 3].copy_(full[1 - self.me][y0 * W * 3: y1 * W * 3])
+
+    loops = [shard.StripLoop(ctxs[r], (lambda r=r: LateCopy(r))) for r in range(2)]
+    try:
+        for k, (clip, col) in enumerate(frames):
+            dclip = torch.from_numpy(clip).cuda()
+            dcol = torch.from_numpy(col.view(np.int32)).cuda()
+
+            def submit(c, k=k, dclip=dclip, dcol=dcol):
+                c.clear((5 * k + 1, 2, 3, 255))
+                c.draw(FLAT, dclip, colors=dcol, device=True)
+            for r in range(2):
+                loops[r].step(submit)
+            torch.cuda.synchronize()
+            for r in range(2):
+                got = full[r].cpu().numpy().reshape(H, W, 3)
+                y0, y1 = rows[r]
+                p0, p1 = rows[1 - r]
+                assert np.array_equal(got[y0:y1], want[k][y0:y1]), f"frame {k} rank {r}: own rows"
+                if k:       # what the late copy delivered: rank 0 stepped first and saw the peer's frame k-1, rank 1 saw rank 0's frame k
+                    assert np.array_equal(got[p0:p1], want[k - 1 + r][p0:p1]), f"frame {k} rank {r}: rows of the peer were touched"
+        for r in range(2):
+            loops[r].finish()
+        torch.cuda.synchronize()
+        for r in range(2):
+            assert np.array_equal(full[r].cpu().numpy().reshape(H, W, 3), want[-1]), f"rank {r}: gathered last frame"
+    finally:
+        for c in ctxs:
+            c.close()

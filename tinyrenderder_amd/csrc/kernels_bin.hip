@@ -294,17 +294,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chunk_spine(const uint32_t* __
                                                                uint32_t* __restrict__ chunk_off,
                                                                unsigned long long* __restrict__ total64) {
     __shared__ uint32_t smem[4];
+    __shared__ unsigned long long smem64[4];
     const uint32_t nchunks = (nblk + EXPAND_CHUNK - 1) / EXPAND_CHUNK;
+    // The offsets are 32-bit by design (a flush holds fewer than 2^32 pairs); the TOTAL is accumulated in 64 bits so that a
+    // flush beyond that limit is seen as such by the host (and by the guards of the kernels queued behind this one)
+    // instead of wrapping: 100 k full-screen triangles at 8192^2 are 6.5e9 pairs.
     unsigned long long running = 0;
     for (uint32_t start = 0; start < nchunks; start += SCAN_THREADS) {
         const uint32_t c = start + threadIdx.x;
-        uint32_t v = 0;
+        unsigned long long v64 = 0;
         if (c < nchunks)
-            for (uint32_t q = c * EXPAND_CHUNK; q < min(nblk, (c + 1) * EXPAND_CHUNK); ++q) v += blk_sums[q];
+            for (uint32_t q = c * EXPAND_CHUNK; q < min(nblk, (c + 1) * EXPAND_CHUNK); ++q) v64 += blk_sums[q];
         uint32_t tot;
-        const uint32_t ex = block_excl_scan(v, smem, &tot);
+        const uint32_t ex = block_excl_scan((uint32_t)v64, smem, &tot);
         if (c < nchunks) chunk_off[c] = (uint32_t)running + ex;
-        running += tot;
+        unsigned long long w64 = v64;
+        for (int o = 32; o; o >>= 1) w64 += __shfl_xor(w64, o);
+        if ((threadIdx.x & 63) == 0) smem64[threadIdx.x >> 6] = w64;
+        __syncthreads();
+        running += smem64[0] + smem64[1] + smem64[2] + smem64[3];
         __syncthreads();
     }
     if (threadIdx.x == 0) *total64 = running;
@@ -315,8 +323,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chunk_spine(const uint32_t* __
 __global__ __launch_bounds__(256) void k_expand(uint32_t first, uint32_t n, int tiles_x, const uint32_t* __restrict__ cnt,
                                                 const uint32_t* __restrict__ blk_sums, const uint32_t* __restrict__ chunk_off,
                                                 uint32_t blk_base, const uint2* __restrict__ tilebox,
-                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                const unsigned long long* __restrict__ pairs_total, uint32_t cap) {
     __shared__ uint32_t smem[4];
+    if (*pairs_total > cap) return;        // the host sized the buffers from an earlier flush: it will grow them and launch again
     const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = first + local;                          // index of the triangle within the flush
     const uint32_t blk = blk_base + blockIdx.x;
@@ -364,21 +374,25 @@ constexpr int RADIX_WAVE_CHUNK = RADIX_CHUNK / 4;
 constexpr int RADIX_ROUNDS = RADIX_WAVE_CHUNK / 64;      // 16
 constexpr int RADIX_MAX_BITS = 8;
 
-__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, uint32_t P, int shift, int bits,
+__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ pairs_total,
+                                                    uint32_t cap, int shift, int bits,
                                                     uint32_t nblocks, uint32_t* __restrict__ hist) {
     __shared__ uint32_t s_cnt[1 << RADIX_MAX_BITS];
+    const unsigned long long P64 = *pairs_total;
+    const uint32_t P = P64 > cap ? 0u : (uint32_t)P64;      // over capacity: nothing was expanded; every block counts nothing
     const uint32_t nb = 1u << bits, mask = nb - 1;
     for (uint32_t b = threadIdx.x; b < nb; b += 256) s_cnt[b] = 0;
     __syncthreads();
     const uint64_t beg = (uint64_t)blockIdx.x * RADIX_CHUNK;
-    uint64_t end = beg + RADIX_CHUNK; if (end > P) end = P;
+    uint64_t end = beg + RADIX_CHUNK; if (end > P) end = P;      // blocks past the last pair (the grid covers the capacity) add zeros
     for (uint64_t p = beg + threadIdx.x; p < end; p += 256) atomicAdd(&s_cnt[(keys[p] >> shift) & mask], 1u);
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nb; b += 256) hist[(size_t)b * nblocks + blockIdx.x] = s_cnt[b];
 }
 
 __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                       uint32_t P, int shift, int bits, uint32_t nblocks,
+                                                       const unsigned long long* __restrict__ pairs_total, uint32_t cap,
+                                                       int shift, int bits, uint32_t nblocks,
                                                        const uint32_t* __restrict__ base,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
     __shared__ uint32_t s_cnt[4][1 << RADIX_MAX_BITS];     // per wave: running count, then (after phase 2) local start
@@ -386,6 +400,9 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
     __shared__ uint32_t s_gbase[1 << RADIX_MAX_BITS];      // global position of the chunk's first pair of each digit
     __shared__ uint32_t s_key[RADIX_CHUNK], s_val[RADIX_CHUNK];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned long long P64 = *pairs_total;
+    const uint32_t P = P64 > cap ? 0u : (uint32_t)P64;
+    if ((uint64_t)blockIdx.x * RADIX_CHUNK >= P) return;     // the grid covers the capacity of the buffers, not the pairs of this flush
     const uint32_t nb = 1u << bits, mask = nb - 1;
     for (uint32_t b = threadIdx.x; b < nb; b += 256) {
         s_cnt[0][b] = 0; s_cnt[1][b] = 0; s_cnt[2][b] = 0; s_cnt[3][b] = 0;
@@ -465,8 +482,10 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void k_bounds(const uint32_t* __restrict__ keys, uint32_t P,
+__global__ __launch_bounds__(256) void k_bounds(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ pairs_total, uint32_t cap,
                                                 uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_end) {
+    const unsigned long long P64 = *pairs_total;
+    const uint32_t P = P64 > cap ? 0u : (uint32_t)P64;
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     uint32_t k = keys[p];
@@ -509,27 +528,32 @@ void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uin
 }
 
 void launch_expand(hipStream_t s, uint32_t first, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* blk_sums,
-                   const uint32_t* chunk_off, uint32_t blk_base, const uint2* tilebox, uint32_t* keys, uint32_t* vals) {
+                   const uint32_t* chunk_off, uint32_t blk_base, const uint2* tilebox, uint32_t* keys, uint32_t* vals,
+                   const unsigned long long* pairs_total, uint32_t cap) {
     if (!n) return;
     hipLaunchKernelGGL(k_expand, dim3(setup_num_blocks(n)), dim3(SETUP_THREADS), 0, s, first, n, tiles_x, cnt, blk_sums, chunk_off,
-                       blk_base, tilebox, keys, vals);
+                       blk_base, tilebox, keys, vals, pairs_total, cap);
 }
 
 uint32_t radix_num_workers(uint32_t P) { return (P + RADIX_CHUNK - 1) / RADIX_CHUNK; }   // = blocks of a pass
 
+// The pair count of the flush stays on the device (`pairs_total`): grids cover `cap`, the capacity of the pair buffers,
+// and blocks past the last pair do nothing, so the host never has to wait for the count before it can queue these.
 void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
-                       uint32_t* vals_out, uint32_t P, int shift, int bits, uint32_t* hist, uint32_t* scan_tmp) {
-    if (!P) return;
-    uint32_t nblk = radix_num_workers(P);
-    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(256), 0, s, keys_in, P, shift, bits, nblk, hist);
+                       uint32_t* vals_out, const unsigned long long* pairs_total, uint32_t cap, int shift, int bits,
+                       uint32_t* hist, uint32_t* scan_tmp) {
+    if (!cap) return;
+    uint32_t nblk = radix_num_workers(cap);
+    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(256), 0, s, keys_in, pairs_total, cap, shift, bits, nblk, hist);
     launch_exclusive_scan(s, hist, hist, (uint64_t)nblk << bits, scan_tmp, nullptr);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(256), 0, s, keys_in, vals_in, P, shift, bits, nblk, hist,
+    hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(256), 0, s, keys_in, vals_in, pairs_total, cap, shift, bits, nblk, hist,
                        keys_out, vals_out);
 }
 
-void launch_bounds(hipStream_t s, const uint32_t* keys, uint32_t P, uint32_t* tile_start, uint32_t* tile_end) {
-    if (!P) return;
-    hipLaunchKernelGGL(k_bounds, dim3((P + 255) / 256), dim3(256), 0, s, keys, P, tile_start, tile_end);
+void launch_bounds(hipStream_t s, const uint32_t* keys, const unsigned long long* pairs_total, uint32_t cap,
+                   uint32_t* tile_start, uint32_t* tile_end) {
+    if (!cap) return;
+    hipLaunchKernelGGL(k_bounds, dim3((cap + 255) / 256), dim3(256), 0, s, keys, pairs_total, cap, tile_start, tile_end);
 }
 
 }  // namespace trgl

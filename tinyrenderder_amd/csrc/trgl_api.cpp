@@ -50,7 +50,8 @@ struct trgl_ctx {
 
     TriRec* recs = nullptr; uint32_t* cnt = nullptr; uint2* tilebox = nullptr;
     // a flush whose first half (setup + binning) has run and whose raster half is still to be launched (trgl_flush_begin)
-    struct { bool active = false; FrameParams fp; int flush_kind = 0; uint32_t P = 0; int cur = 0; uint64_t N = 0; } rp;
+    struct { bool active = false; FrameParams fp; int flush_kind = 0; uint32_t cap = 0; int cur = 0; uint64_t N = 0; bool binned = false; } rp;
+    hipEvent_t ev_pairs = nullptr;      // recorded behind the copy of the flush's pair count into pinned memory
     uint32_t* idbuf = nullptr; size_t cap_idbuf = 0;        // visibility buffer of PHONG / EYE flushes, [H][W]
     uint32_t* blk_sums = nullptr; size_t cap_blk = 0;       // pairs per setup block of 256 triangles
     uint32_t* chunk_off = nullptr; size_t cap_chunk = 0;    // pairs before every 16th setup block
@@ -165,6 +166,7 @@ int trgl_create(int device, int width, int height, int bpp, trgl_ctx** out) {
     CRE(hipMalloc((void**)&c->stats_dev, sizeof(DevStats)));
     CRE(hipHostMalloc((void**)&c->stats_pinned, sizeof(DevStats)));
     for (int i = 0; i < 6; ++i) CRE(hipEventCreate(&c->ev[i]));
+    CRE(hipEventCreateWithFlags(&c->ev_pairs, hipEventDisableTiming));
 #undef CRE
     // init_viewport(0,0,W,H), our_gl.cpp:59-69
     trgl_init_viewport(c, 0, 0, width, height);
@@ -185,6 +187,7 @@ int trgl_destroy(trgl_ctx* c) {
     if (c->draws_pinned) (void)hipHostFree(c->draws_pinned);
     if (c->stats_pinned) (void)hipHostFree(c->stats_pinned);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->ev_pairs) (void)hipEventDestroy(c->ev_pairs);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return TRGL_OK;
@@ -212,7 +215,6 @@ int trgl_init_viewport(trgl_ctx* c, int x, int y, int w, int h) {          // ou
 
 int trgl_clear(trgl_ctx* c, const uint8_t bgra[4], double z_clear) {
     CHKCTX(c);
-    if (c->rp.active) { int fr = trgl_flush_end(c); if (fr) return fr; }
     if (c->rp.active) { int fr = trgl_flush_end(c); if (fr) return fr; }
     if (!c->draws.empty()) { int r = trgl_flush(c); if (r) return r; }      // earlier draws come first
     static const uint8_t dflt[4] = { 0, 0, 0, 255 };                         // TGAColor(), tgaimage.h:33
@@ -414,9 +416,54 @@ int trgl_flush(trgl_ctx* c) {
     return r ? r : trgl_flush_end(c);
 }
 
+// expand -> stable radix passes by tile id -> per-tile bounds, for pair buffers of capacity `cap`.  All of it reads the pair
+// count from device memory; when the count exceeds `cap` every kernel here does nothing.
+static int queue_binning(trgl_ctx* c, uint32_t cap, int* cur_out) {
+    hipStream_t s = c->stream;
+    const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
+    const unsigned long long* pairs_dev = &c->stats_dev->pairs_total;
+    int r;
+    uint32_t blk_base = 0;
+    for (auto& d : c->draws) {
+        launch_expand(s, d.first, d.n, c->tiles_x, c->cnt, c->blk_sums, c->chunk_off, blk_base, c->tilebox, c->keys[0], c->vals[0], pairs_dev, cap);
+        blk_base += setup_num_blocks(d.n);
+    }
+    int key_bits = 1; while ((size_t(1) << key_bits) < ntiles) ++key_bits;
+    int passes = (key_bits + 7) / 8;
+    int bits_per = (key_bits + passes - 1) / passes;
+    size_t hist_need = ((size_t)radix_num_workers(cap) << bits_per) + 16;
+    if ((r = grow(c, c->hist, c->cap_hist, hist_need))) return r;
+    if ((r = grow(c, c->scan_tmp, c->cap_scan, (size_t)scan_num_blocks(hist_need) + 16))) return r;
+    int cur = 0;
+    for (int ps = 0; ps < passes; ++ps) {
+        launch_radix_pass(s, c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1], pairs_dev, cap, ps * bits_per, bits_per,
+                          c->hist, c->scan_tmp);
+        cur ^= 1;
+    }
+    launch_bounds(s, c->keys[cur], pairs_dev, cap, c->tile_start, c->tile_end);
+    *cur_out = cur;
+    return TRGL_OK;
+}
+
+static int grow_pairs(trgl_ctx* c, size_t need) {
+    if (need <= c->cap_pairs) return TRGL_OK;
+    size_t ncap = need + need / 4 + 1024;
+    if (ncap > 0xfffffff0ull) ncap = 0xfffffff0ull;
+    int r;
+    for (int k = 0; k < 2; ++k) {
+        if ((r = realloc_dev(c, (void**)&c->keys[k], ncap * 4))) return r;
+        if ((r = realloc_dev(c, (void**)&c->vals[k], ncap * 4))) return r;
+    }
+    c->cap_pairs = ncap;
+    return TRGL_OK;
+}
+
 // First half of a flush: per-triangle setup and the stable tile binning.  Touches neither the framebuffer nor the
 // z-buffer, so a caller may let it overlap with whatever still reads them (bench.py: the RCCL gather of the
-// previous frame's strips).
+// previous frame's strips).  The host does not wait for anything here: the number of (tile, triangle) pairs stays on the
+// device, the binning kernels are queued for the capacity the pair buffers already have (an earlier flush's count + 25 %,
+// or 2 pairs per triangle the first time), and trgl_flush_end checks the count - which has reached pinned memory long
+// before the binning is through - and queues them again in the rare case that the buffers were too small.
 int trgl_flush_begin(trgl_ctx* c) {
     CHKCTX(c);
     if (c->rp.active) return TRGL_OK;
@@ -448,7 +495,8 @@ int trgl_flush_begin(trgl_ctx* c) {
     }
 
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    uint32_t P = 0;
+    uint32_t cap = 0;
+    int cur = 0;
     if (N) {
         // grow per-triangle buffers together
         if (N > c->cap_tris) {
@@ -458,6 +506,7 @@ int trgl_flush_begin(trgl_ctx* c) {
             if ((r = realloc_dev(c, (void**)&c->tilebox, ncap * sizeof(uint2)))) return r;
             c->cap_tris = ncap;
         }
+        if (c->cap_pairs == 0 && (r = grow_pairs(c, (size_t)2 * N + 4096))) return r;      // first flush: a guess, checked in trgl_flush_end
         std::memcpy(c->draws_pinned, c->draws.data(), c->draws.size() * sizeof(DrawDesc));
         HIPCHK(c, hipMemcpyAsync(c->draws_dev, c->draws_pinned, c->draws.size() * sizeof(DrawDesc), hipMemcpyHostToDevice, s));
         uint32_t nblk = 0;
@@ -474,46 +523,16 @@ int trgl_flush_begin(trgl_ctx* c) {
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
         launch_chunk_spine(s, c->blk_sums, nblk, c->chunk_off, &c->stats_dev->pairs_total);
         HIPCHK(c, hipMemcpyAsync(&c->stats_pinned->pairs_total, &c->stats_dev->pairs_total, 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        unsigned long long P64 = c->stats_pinned->pairs_total;
-        if (P64 > 0xfffffff0ull) return fail(c, TRGL_E_UNSUPPORTED, "flush: more than 2^32 triangle-tile pairs; submit in smaller batches");
-        P = (uint32_t)P64;
-    } else if (c->profiling) {
-        HIPCHK(c, hipEventRecord(c->ev[1], s));
-    }
-    HIPCHK(c, hipMemsetAsync(c->tile_start, 0, ntiles * 8, s));                // tile_start and tile_end
-    int cur = 0;
-    if (P) {
-        if (P > c->cap_pairs) {
-            size_t ncap = (size_t)P + P / 4 + 1024;
-            for (int k = 0; k < 2; ++k) {
-                if ((r = realloc_dev(c, (void**)&c->keys[k], ncap * 4))) return r;
-                if ((r = realloc_dev(c, (void**)&c->vals[k], ncap * 4))) return r;
-            }
-            c->cap_pairs = ncap;
-        }
-        {
-            uint32_t blk_base = 0;
-            for (auto& d : c->draws) {
-                launch_expand(s, d.first, d.n, c->tiles_x, c->cnt, c->blk_sums, c->chunk_off, blk_base, c->tilebox, c->keys[0], c->vals[0]);
-                blk_base += setup_num_blocks(d.n);
-            }
-        }
-        int key_bits = 1; while ((size_t(1) << key_bits) < ntiles) ++key_bits;
-        int passes = (key_bits + 7) / 8;
-        int bits_per = (key_bits + passes - 1) / passes;
-        size_t hist_need = ((size_t)radix_num_workers(P) << bits_per) + 16;
-        if ((r = grow(c, c->hist, c->cap_hist, hist_need))) return r;
-        if ((r = grow(c, c->scan_tmp, c->cap_scan, (size_t)scan_num_blocks(hist_need) + 16))) return r;
-        for (int ps = 0; ps < passes; ++ps) {
-            launch_radix_pass(s, c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1], P, ps * bits_per, bits_per,
-                              c->hist, c->scan_tmp);
-            cur ^= 1;
-        }
-        launch_bounds(s, c->keys[cur], P, c->tile_start, c->tile_end);
+        HIPCHK(c, hipEventRecord(c->ev_pairs, s));
+        HIPCHK(c, hipMemsetAsync(c->tile_start, 0, ntiles * 8, s));                // tile_start and tile_end
+        cap = (uint32_t)c->cap_pairs;
+        if ((r = queue_binning(c, cap, &cur))) return r;
+    } else {
+        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
+        HIPCHK(c, hipMemsetAsync(c->tile_start, 0, ntiles * 8, s));
     }
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    c->rp.active = true; c->rp.fp = fp; c->rp.flush_kind = flush_kind; c->rp.P = P; c->rp.cur = cur; c->rp.N = N;
+    c->rp.active = true; c->rp.fp = fp; c->rp.flush_kind = flush_kind; c->rp.cap = cap; c->rp.cur = cur; c->rp.N = N;
     return TRGL_OK;
 }
 
@@ -525,9 +544,25 @@ int trgl_flush_end(trgl_ctx* c) {
     int r;
     hipStream_t s = c->stream;
     const FrameParams fp = c->rp.fp;
-    const int flush_kind = c->rp.flush_kind, cur = c->rp.cur;
-    const uint32_t P = c->rp.P;
+    const int flush_kind = c->rp.flush_kind;
+    int cur = c->rp.cur;
     const uint64_t N = c->rp.N;
+    uint32_t P = 0;
+    if (N) {
+        // the pair count was copied to pinned memory right after k_setup; the GPU is busy with the binning queued behind it
+        HIPCHK(c, hipEventSynchronize(c->ev_pairs));
+        const unsigned long long P64 = c->stats_pinned->pairs_total;
+        if (P64 > 0xfffffff0ull) {
+            c->draws.clear(); c->queued_tris = 0;          // nothing of this flush was drawn (every binning kernel saw the overflow)
+            return fail(c, TRGL_E_UNSUPPORTED, "flush: more than 2^32 triangle-tile pairs; submit in smaller batches");
+        }
+        P = (uint32_t)P64;
+        if (P > c->rp.cap) {                               // the buffers were too small: the queued binning did nothing
+            if ((r = grow_pairs(c, P))) return r;
+            if ((r = queue_binning(c, (uint32_t)c->cap_pairs, &cur))) return r;
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], s));
+        }
+    }
     // with no pairs every tile list is empty; the kernel must not (and does not) dereference these, but give it
     // valid addresses anyway
     const TriRec* recs_arg = c->recs ? c->recs : reinterpret_cast<const TriRec*>(c->tile_start);

@@ -44,3 +44,43 @@ def reduce_stats(stats, device=None, group=None):
     dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
     zlo, zhi = float(lo.item()), float(hi.item())
     return (tri, int(s.item()), x0, y0, x1, y1, zlo, zhi, float(np.copysign(1.0, zlo)), float(np.copysign(1.0, zhi)))
+
+
+class _DevBuf:
+    """Expose a raw device pointer to torch through __cuda_array_interface__."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def framebuffer_tensor(ctx):
+    """A flat uint8 torch tensor that ALIASES the context's framebuffer in HBM (the in-place gather writes into it)."""
+    import torch
+    return torch.as_tensor(_DevBuf(ctx.framebuffer_ptr, ctx.width * ctx.height * ctx.bpp), device="cuda")
+
+
+class StripLoop:
+    """The per-frame sequence of ONE rank of a multi-GPU render, exactly as bench.py runs it over RCCL:
+
+        submit (clear + draws)  ->  flush_begin (setup + binning: touches neither buffer)  ->  wait for the previous
+        frame's gather  ->  flush_end (raster: writes only the rows this rank owns)  ->  start this frame's gather
+
+    `gather()` starts joining the strips into this rank's full framebuffer and returns a handle with wait() (or None).  The
+    gather of frame k therefore overlaps with the setup and binning of frame k + 1, and the rows a rank does not own keep
+    the previous frame's pixels until the next gather lands."""
+
+    def __init__(self, ctx, gather):
+        self.ctx, self.gather, self.pending = ctx, gather, None
+
+    def step(self, submit):
+        submit(self.ctx)
+        self.ctx.flush_begin()
+        if self.pending is not None:
+            self.pending.wait()              # the raster must not overwrite the strip while the gather still reads it
+        self.ctx.flush_end()
+        self.pending = self.gather()
+
+    def finish(self):
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
