@@ -20,10 +20,23 @@ struct Reader {
     void align8() { pos = (pos + 7) & ~size_t(7); }
 };
 
-// stands in for the reference's Model (model.h:46-131): per-face-vertex attributes + material[0] maps
+// stands in for the reference's Model (model.h:46-131): per-face-vertex attributes + material[0] maps, and the same data as
+// the indexed mesh the reference keeps (Model::vertices / indices, model.h:114-115; Vertex = model.h:14-20)
+struct Vertex { vec3 position, normal; vec2 texcoord; vec3 tangent, bitangent; };
 struct Model {
     std::vector<double> pos, nrm, tex;       // [nfaces][3][3], [nfaces][3][3], [nfaces][3][2]
+    std::vector<Vertex> vertices;
+    std::vector<unsigned int> indices;
     TGAImage diffuse, normalmap, specular;
+    void build_indexed() {                   // one vertex per face corner (no sharing): the order of the faces is what matters
+        vertices.resize(pos.size() / 3); indices.resize(pos.size() / 3);
+        for (size_t i = 0; i < vertices.size(); ++i) {
+            vertices[i].position = make_vec3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+            vertices[i].normal = make_vec3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
+            vertices[i].texcoord = make_vec2(tex[2 * i], tex[2 * i + 1]);
+            indices[i] = (unsigned int)i;
+        }
+    }
     int nfaces() const { return int(pos.size() / 9); }
     vec3 vert(int f, int v) const { return make_vec3(pos[(f * 3 + v) * 3], pos[(f * 3 + v) * 3 + 1], pos[(f * 3 + v) * 3 + 2]); }
     vec3 normal(int f, int v) const { return make_vec3(nrm[(f * 3 + v) * 3], nrm[(f * 3 + v) * 3 + 1], nrm[(f * 3 + v) * 3 + 2]); }
@@ -44,7 +57,8 @@ static TGAImage read_texture(Reader& r) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 3) { std::fprintf(stderr, "usage: demo_main <model.bin> <out.bin> [out.tga]\n"); return 1; }
+    if (argc < 3) { std::fprintf(stderr, "usage: demo_main <model.bin> <out.bin> [out.tga [postprocess_basename [loop]]]\n"); return 1; }
+    const bool use_draw_model = !(argc > 5 && std::strcmp(argv[5], "loop") == 0);    // "loop": the reference's per-face rasterize() loop
     Reader r;
     if (!r.load(argv[1]) || std::memcmp(&r.buf[0], "TRGMDL01", 8) != 0) { std::fprintf(stderr, "bad model file\n"); return 2; }
     r.pos = 8;
@@ -61,6 +75,7 @@ int main(int argc, char** argv) {
     head.pos.resize(size_t(nfaces) * 9); head.nrm.resize(size_t(nfaces) * 9); head.tex.resize(size_t(nfaces) * 6);
     r.read(head.pos.data(), head.pos.size() * 8); r.read(head.nrm.data(), head.nrm.size() * 8); r.read(head.tex.data(), head.tex.size() * 8);
     head.diffuse = read_texture(r); head.normalmap = read_texture(r); head.specular = read_texture(r);
+    head.build_indexed();
     const int nflat = r.get<int32_t>(); r.get<int32_t>();
     std::vector<double> flat_clip(size_t(nflat) * 12); std::vector<uint32_t> flat_col(nflat);
     r.read(flat_clip.data(), flat_clip.size() * 8); r.read(flat_col.data(), flat_col.size() * 4);
@@ -79,13 +94,16 @@ int main(int argc, char** argv) {
     PhongShader head_shader(&head);
     head_shader.initLightDirections(key_light_dir, fill_light_dir, rim_light_dir);
     head_shader.normal_map_strength = strength;
-    for (int face = 0; face < head.nfaces(); ++face) {
-        vec4 clip_space_triangle[3];
-        for (int vertex = 0; vertex < 3; ++vertex) clip_space_triangle[vertex] = head_shader.vertex(face, vertex);
-        rasterize(clip_space_triangle, head_shader, framebuffer);
+    if (use_draw_model) {
+        gl_draw_model(head, head_shader, framebuffer);       // the whole face loop in one call, vertex stage on the device
+    } else {
+        for (int face = 0; face < head.nfaces(); ++face) {
+            vec4 clip_space_triangle[3];
+            for (int vertex = 0; vertex < 3; ++vertex) clip_space_triangle[vertex] = head_shader.vertex(face, vertex);
+            rasterize(clip_space_triangle, head_shader, framebuffer);
+        }
     }
-    gl_flush(framebuffer);                                   // the caller is about to read `zbuffer`
-    std::vector<double> zbuffer_before_eyes = zbuffer;       // main.cpp:700
+    std::vector<double> zbuffer_before_eyes = zbuffer;       // main.cpp:700, unchanged: the proxy completes the pending draws
 
     // ---- eyes pass, main.cpp:711-721 (every third face of the same mesh stands in for the eye model) ----
     EyeShader eye_shader(&head);
@@ -95,9 +113,7 @@ int main(int argc, char** argv) {
         for (int vertex = 0; vertex < 3; ++vertex) clip_space_triangle[vertex] = eye_shader.vertex(face, vertex);
         rasterize(clip_space_triangle, eye_shader, framebuffer);
     }
-    gl_flush(framebuffer);
-    zbuffer = zbuffer_before_eyes;                           // main.cpp:730
-    gl_zbuffer_modified();
+    zbuffer = zbuffer_before_eyes;                           // main.cpp:730, unchanged: the eyes are drawn before the depths are replaced
 
     // ---- an overlay of flat triangles (BASELINE config 0's "flat shader") ----
     FlatShader flat;
@@ -128,7 +144,8 @@ int main(int argc, char** argv) {
 
     std::ofstream out(argv[2], std::ios::binary);
     out.write(reinterpret_cast<const char*>(framebuffer.buffer()), std::streamsize(size_t(WIDTH) * HEIGHT * bpp));
-    out.write(reinterpret_cast<const char*>(zbuffer.data()), std::streamsize(zbuffer.size() * 8));
+    const std::vector<double>& depths = zbuffer;
+    out.write(reinterpret_cast<const char*>(depths.data()), std::streamsize(depths.size() * 8));
     out.write(line, std::streamsize(std::strlen(line)));
     gl_shutdown();
     return out ? 0 : 3;

@@ -260,6 +260,14 @@ void trgl_obj_free(double* vertices, uint32_t* indices);
  * rounding midpoints, numerators next to u.z, signed zeros).  *mismatches must come back 0. */
 int trgl_selftest_division(trgl_ctx* ctx, uint64_t samples, uint64_t seed, uint64_t* mismatches);
 
+/*
+ * Diagnostics: the samplers' nearest-texel fetch (Model::diffuse / normal / specular, model.cpp:415-459:
+ * clamp(int(uv * size), 0, size - 1) then TGAImage::get, tgaimage.cpp:24-30) of texture `slot` at n host-side uv pairs;
+ * out receives 5 bytes per sample: bgra[4], TGAColor::bytespp.  An empty slot samples as opaque white (model.cpp:416-418).
+ * The tests compare it with what the reference's compiled IShader::sample2D (our_gl.h:38-44) returns.
+ */
+int trgl_selftest_sampler(trgl_ctx* ctx, int slot, const double* uv, uint64_t n, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

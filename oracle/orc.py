@@ -82,6 +82,8 @@ def lib():
         L.orc_fragment.argtypes = [C.c_int, C.POINTER(Uniforms), C.POINTER(Texture), C.c_void_p, C.c_uint32,
                                    C.POINTER(C.c_double), C.POINTER(C.c_uint8)]
         L.orc_fragment.restype = C.c_int
+        L.orc_tex_fetch.argtypes = [C.POINTER(Texture), C.c_void_p, C.c_void_p]
+        L.orc_tex_fetch.restype = C.c_int
         L.orc_normalized3.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_mat4_mul_dir.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_interp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -293,3 +295,35 @@ def ssao(z):
 def composite(fb, ao):
     fb = np.ascontiguousarray(fb, np.uint8); ao = np.ascontiguousarray(ao, np.uint8); h, w, _ = fb.shape
     out = np.empty((h, w, 3), np.uint8); lib().orc_composite(fb.ctypes.data, ao.ctypes.data, w, h, out.ctypes.data); return out
+
+
+def tex_fetch(texels, uv):
+    """The samplers' nearest-texel fetch (model.cpp:415-425) through the C restatement: [n, 5] uint8 = bgra[4], bytespp."""
+    t = np.ascontiguousarray(texels, np.uint8)
+    if t.ndim == 2:
+        t = t[..., None]
+    tex = Texture(t.ctypes.data, t.shape[1], t.shape[0], t.shape[2])
+    uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+    out = np.zeros((uv.shape[0], 5), np.uint8)
+    px = np.zeros(4, np.uint8)
+    for i in range(uv.shape[0]):
+        out[i, 4] = lib().orc_tex_fetch(C.byref(tex), uv[i].ctypes.data, px.ctypes.data)
+        out[i, :4] = px
+    return out
+
+
+def run_reference_sample2d(texels, uv):
+    """IShader::sample2D (our_gl.h:38-44) of the compiled reference on a texture and uv list (build container only): [n, 5] uint8."""
+    t = np.ascontiguousarray(texels, np.uint8)
+    if t.ndim == 2:
+        t = t[..., None]
+    uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+    with tempfile.TemporaryDirectory() as d:
+        ip, op = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(ip, "wb") as f:
+            f.write(struct.pack("<4i", t.shape[1], t.shape[0], t.shape[2], uv.shape[0]))
+            f.write(_pad8(t.tobytes()))
+            f.write(uv.tobytes())
+        subprocess.run([REF_HARNESS, "sample2d", ip, op], check=True)
+        raw = np.frombuffer(open(op, "rb").read(), np.uint8).reshape(-1, 8)
+    return raw[:, :5].copy()

@@ -203,6 +203,26 @@ int run_tgaread(const char* in_path, const char* out_path) {
     return out ? 0 : 3;
 }
 
+// sample2d: input = int32 w, h, bpp, count + texels (padded to 8) + count x 2 doubles (uv); output per sample: bgra[4], bytespp,
+// 3 pad bytes, from the reference's own IShader::sample2D (our_gl.h:38-44) -> TGAImage::get (tgaimage.cpp:24-30).  Model::diffuse /
+// normal / specular (model.cpp:415-459, not compilable here: Assimp) use the same clamp(int(uv * size), 0, size - 1) + get().
+int run_sample2d(const char* in_path, const char* out_path) {
+    Reader r;
+    if (!r.load(in_path)) return 2;
+    int w = r.get<int32_t>(), h = r.get<int32_t>(), bpp = r.get<int32_t>(), count = r.get<int32_t>();
+    TGAImage img(w, h, bpp);
+    std::memcpy(img.buffer(), r.take((size_t)w * h * bpp), (size_t)w * h * bpp);
+    r.align8();
+    std::ofstream out(out_path, std::ios::binary);
+    for (int i = 0; i < count; ++i) {
+        vec2 uv; uv.x = r.get<double>(); uv.y = r.get<double>();
+        TGAColor c = IShader::sample2D(img, uv);
+        unsigned char rec[8] = { c.bgra[0], c.bgra[1], c.bgra[2], c.bgra[3], c.bytespp, 0, 0, 0 };
+        out.write((const char*)rec, 8);
+    }
+    return out ? 0 : 3;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -210,6 +230,7 @@ int main(int argc, char** argv) {
     if (argc == 4 && std::strcmp(argv[1], "vecops") == 0) return run_vecops(argv[2], argv[3]);
     if (argc == 4 && std::strcmp(argv[1], "tga") == 0) return run_tga(argv[2], argv[3]);
     if (argc == 4 && std::strcmp(argv[1], "tgaread") == 0) return run_tgaread(argv[2], argv[3]);
-    std::fprintf(stderr, "usage: ref_harness scene|vecops|tga|tgaread <in> <out>\n");
+    if (argc == 4 && std::strcmp(argv[1], "sample2d") == 0) return run_sample2d(argv[2], argv[3]);
+    std::fprintf(stderr, "usage: ref_harness scene|vecops|tga|tgaread|sample2d <in> <out>\n");
     return 1;
 }

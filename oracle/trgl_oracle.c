@@ -113,6 +113,13 @@ static color_t tex_fetch(const orc_texture* t, const double uv[2]) {
     int y = iclamp(x86_cvttsd2si(uv[1] * t->h), 0, t->h - 1);
     return color_from_ptr(t->data + ((size_t)x + (size_t)y * t->w) * t->bpp, t->bpp);
 }
+/* the clamped nearest-texel fetch on its own, so that it can be pinned against the reference's compiled
+ * IShader::sample2D (our_gl.h:38-44) + TGAImage::get (tgaimage.cpp:24-30): same int(uv * size) truncation, same clamp */
+int orc_tex_fetch(const orc_texture* t, const double uv[2], uint8_t bgra[4]) {
+    color_t c = tex_fetch(t, uv);
+    for (int i = 0; i < 4; ++i) bgra[i] = c.bgra[i];
+    return c.bytespp;
+}
 static color_t model_diffuse(const orc_texture* textures, int slot, const double uv[2]) {
     const orc_texture* t = tex_slot(textures, slot);                    /* model.cpp:415-426 */
     if (!t) { color_t c = { { 255, 255, 255, 255 }, 4 }; return c; }

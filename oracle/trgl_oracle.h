@@ -51,6 +51,8 @@ void orc_rasterize(orc_target* t, int shader_kind, const trgl_uniforms* u,
 
 /* One IShader::fragment() call (our_gl.cpp:187) of the given kind: bary is the perspective-correct
  * barycentric vector the rasterizer passes.  Returns bytespp of the colour (tgaimage.h:31). */
+/* nearest-texel fetch with the samplers' index math (model.cpp:415-425 = our_gl.h:38-44); returns TGAColor::bytespp */
+int orc_tex_fetch(const orc_texture* t, const double uv[2], uint8_t bgra[4]);
 int orc_fragment(int shader_kind, const trgl_uniforms* u, const orc_texture* textures,
                  const double* varyings, uint32_t packed_color, const double bary[3], uint8_t out_bgra[4]);
 

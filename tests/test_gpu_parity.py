@@ -595,3 +595,19 @@ def test_strip_loop_two_contexts_interleaved_frames():
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("i", range(5))
+def test_device_sampler_equals_reference_sample2d(i):
+    """The device samplers' texel fetch (tex_fetch in kernels_raster.hip, through trgl_selftest_sampler) against the
+    fixtures taken from the reference's compiled IShader::sample2D + TGAImage::get: NaN / inf / negative / huge uv (the
+    x86 cvttsd2si result INT_MIN clamps to texel 0), every texel boundary +- 1 ulp, 1 / 3 / 4 bytes per pixel."""
+    g = np.load(os.path.join(HERE, "golden", "sampler_golden.npz"))
+    tex, uv, want = g[f"tex{i}"], g[f"uv{i}"].view(np.float64), g[f"out{i}"]
+    with Context(32, 32, 3) as ctx:
+        ctx.upload_texture(3, tex)
+        got = ctx.selftest_sampler(3, uv)
+        empty = ctx.selftest_sampler(5, uv[:4])
+    bad = np.argwhere((got != want).any(axis=1))
+    assert bad.size == 0, f"{len(bad)} samples differ, first uv {uv[bad[0, 0]]}: {got[bad[0, 0]]} vs {want[bad[0, 0]]}"
+    assert (empty == np.array([255, 255, 255, 255, 4], np.uint8)).all()

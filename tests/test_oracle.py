@@ -112,3 +112,25 @@ def test_golden_is_reproducible_from_reference():
                                     [(k, None, cl, v, co) for k, u, cl, v, co in case["draws"]])
     g = GOLDEN["flat_persp_512"]
     assert (scenes.digest(fb), scenes.digest(z), line) == (g["fb"], g["z"], g["stats"])
+
+
+# ---- samplers: index math pinned by the reference's compiled IShader::sample2D (our_gl.h:38-44) ----------------------------------
+SAMPLER_GOLDEN = np.load(os.path.join(HERE, "golden", "sampler_golden.npz"))
+
+
+@pytest.mark.parametrize("i", range(5))
+def test_sampler_restatement_equals_reference_sample2d(i):
+    """orc tex_fetch (model.cpp:415-425 restated) vs the fixtures tests/golden/make_sampler_golden.py took from the compiled
+    reference: NaN, +-inf, negatives, exactly 1.0, 1e300, values beyond INT_MAX after scaling, every texel boundary +- 1 ulp,
+    textures of 1 / 3 / 4 bytes per pixel, 1x1 and odd sizes."""
+    tex, uv, want = SAMPLER_GOLDEN[f"tex{i}"], SAMPLER_GOLDEN[f"uv{i}"].view(np.float64), SAMPLER_GOLDEN[f"out{i}"]
+    got = orc.tex_fetch(tex, uv)
+    bad = np.argwhere((got != want).any(axis=1))
+    assert bad.size == 0, f"{len(bad)} samples differ, first uv {uv[bad[0, 0]]}"
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not orc.ref_available(), reason="oracle/_ref not built (reference tree absent)")
+def test_sampler_fixture_is_what_the_reference_returns_now():
+    tex, uv, want = SAMPLER_GOLDEN["tex1"], SAMPLER_GOLDEN["uv1"].view(np.float64), SAMPLER_GOLDEN["out1"]
+    assert np.array_equal(orc.run_reference_sample2d(tex, uv), want)

@@ -37,7 +37,12 @@ def _write_model(path, W, H, bpp, hd, strength, textures, fclip, fcol):
 
 
 @pytest.mark.gpu
-def test_main_cpp_shaped_demo_matches_oracle(tmp_path):
+@pytest.mark.parametrize("mode", ["model", "loop"])
+def test_main_cpp_shaped_demo_matches_oracle(tmp_path, mode):
+    """mode "model": the head pass is ONE gl_draw_model() call (vertex stage on the device, trgl_draw_indexed); mode "loop": the
+    reference's per-face vertex() + rasterize() loop.  In both, `zbuffer` is read and assigned exactly as main.cpp:700,730 do
+    (the proxy completes the batched eye triangles BEFORE the saved depths replace them: the eyes must show in the colours
+    and not in the depths)."""
     assert os.path.exists(DEMO), "examples/demo_main not built: run __graft_entry__.build()"
     W, H, bpp = 320, 240, 3
     hd = scenes.head_standin(3, W, H)
@@ -46,7 +51,7 @@ def test_main_cpp_shaped_demo_matches_oracle(tmp_path):
     model, out, tga = tmp_path / "model.bin", tmp_path / "out.bin", tmp_path / "out.tga"
     _write_model(model, W, H, bpp, hd, 0.75, (d, n, s), fclip, fcol)
     post = str(tmp_path / "post")
-    r = subprocess.run([DEMO, str(model), str(out), str(tga), post], capture_output=True, text=True)
+    r = subprocess.run([DEMO, str(model), str(out), str(tga), post] + (["loop"] if mode == "loop" else []), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     raw = open(out, "rb").read()
     fb = np.frombuffer(raw, np.uint8, W * H * bpp).reshape(H, W, bpp)

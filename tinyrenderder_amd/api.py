@@ -28,7 +28,7 @@ SYMBOLS = [
     "trgl_write_framebuffer", "trgl_read_zbuffer", "trgl_write_zbuffer", "trgl_get_stats", "trgl_reset_stats",
     "trgl_format_stats", "trgl_framebuffer_device_ptr", "trgl_zbuffer_device_ptr", "trgl_stream", "trgl_set_stream",
     "trgl_set_profiling", "trgl_get_phase_ms", "trgl_reset_phase_ms", "trgl_get_last_flush_info",
-    "trgl_selftest_division", "trgl_tga_max_size", "trgl_tga_encode", "trgl_tga_info", "trgl_tga_decode", "trgl_draw_indexed", "trgl_ssao_defaults",
+    "trgl_selftest_division", "trgl_selftest_sampler", "trgl_tga_max_size", "trgl_tga_encode", "trgl_tga_info", "trgl_tga_decode", "trgl_draw_indexed", "trgl_ssao_defaults",
     "trgl_postprocess", "trgl_obj_load", "trgl_obj_free",
 ]
 
@@ -128,6 +128,7 @@ def load_library(path: str = None):
     L.trgl_reset_phase_ms.argtypes = [vp]
     L.trgl_get_last_flush_info.argtypes = [vp, u64p, u64p, u64p]
     L.trgl_selftest_division.argtypes = [vp, C.c_uint64, C.c_uint64, u64p]
+    L.trgl_selftest_sampler.argtypes = [vp, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
     L.trgl_draw_indexed.argtypes = [vp, C.c_int, C.POINTER(Uniforms), dp, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int]
     L.trgl_ssao_defaults.argtypes = [C.POINTER(SsaoParams)]
     L.trgl_ssao_defaults.restype = None
@@ -393,6 +394,13 @@ class Context:
         bad = C.c_uint64()
         self._chk(self.L.trgl_selftest_division(self.h, samples, seed, C.byref(bad)))
         return bad.value
+
+    def selftest_sampler(self, slot: int, uv) -> np.ndarray:
+        """The device samplers' texel fetch of texture `slot` at uv [n,2]: [n,5] uint8 = bgra[4], bytespp."""
+        uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+        out = np.zeros((uv.shape[0], 5), np.uint8)
+        self._chk(self.L.trgl_selftest_sampler(self.h, slot, uv.ctypes.data, uv.shape[0], out.ctypes.data))
+        return out
 
     def last_flush_info(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -931,6 +931,18 @@ __global__ void k_selftest_division(unsigned long long n_per_thread, unsigned lo
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// ---- self-test of the samplers' index math: tex_fetch on given uv (the fixtures come from the compiled reference's
+// IShader::sample2D, tests/golden/sampler_golden.npz) ---------------------------------------------------------------
+__global__ void k_selftest_sampler(const DevTexture* __restrict__ tex, int slot, const double* __restrict__ uv, unsigned long long n,
+                                   uint8_t* __restrict__ out) {
+    const unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevTexture* t = tex_slot(tex, slot);
+    Color c = t ? tex_fetch(t, uv + 2 * i) : Color{ 0xffffffffu, 4 };        // a missing map samples as opaque white (model.cpp:416-418)
+    for (int k = 0; k < 4; ++k) out[5 * i + k] = (uint8_t)(c.bgra >> (8 * k));
+    out[5 * i + 4] = (uint8_t)c.bytespp;
+}
+
 // Work items of the raster kernel: one per tile row-band (see k_raster).  A tile is cut into bands when its list
 // is longer than `split_len` (chosen by the host relative to the mean list length).  Tiles outside the strip's
 // tile rows, and empty tiles of a flush that does not start from clear, get no item.
@@ -1004,6 +1016,10 @@ namespace trgl {
 
 void launch_selftest_division(hipStream_t s, unsigned long long n_per_thread, unsigned long long seed, unsigned long long* mismatches) {
     hipLaunchKernelGGL(k_selftest_division, dim3(1024), dim3(256), 0, s, n_per_thread, seed, mismatches);
+}
+
+void launch_selftest_sampler(hipStream_t s, const DevTexture* tex, int slot, const double* uv, unsigned long long n, uint8_t* out) {
+    if (n) hipLaunchKernelGGL(k_selftest_sampler, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tex, slot, uv, n, out);
 }
 
 uint32_t raster_max_items(const FrameParams& fp, uint64_t pairs, uint32_t split_len) {

@@ -43,6 +43,7 @@ void launch_ssao(hipStream_t s, const double* zb, int W, int H, const double* di
                  double radius, double threshold, double intensity, uint8_t* out);
 void launch_composite(hipStream_t s, const uint8_t* fb, int bpp, const uint8_t* ao, int W, int H, uint8_t* out);
 
+void launch_selftest_sampler(hipStream_t s, const DevTexture* tex, int slot, const double* uv, unsigned long long n, uint8_t* out);
 void launch_selftest_division(hipStream_t s, unsigned long long n_per_thread, unsigned long long seed,
                               unsigned long long* mismatches);
 

@@ -747,6 +747,23 @@ int trgl_selftest_division(trgl_ctx* c, uint64_t samples, uint64_t seed, uint64_
     return TRGL_OK;
 }
 
+int trgl_selftest_sampler(trgl_ctx* c, int slot, const double* uv, uint64_t n, uint8_t* out) {
+    CHKCTX(c);
+    if (!uv || !out) return fail(c, TRGL_E_INVALID, "trgl_selftest_sampler: null argument");
+    if (slot < 0 || slot >= TRGL_MAX_TEXTURES) return fail(c, TRGL_E_INVALID, "trgl_selftest_sampler: bad slot");
+    int r = trgl_flush(c); if (r) return r;
+    if (!n) return TRGL_OK;
+    double* d_uv = nullptr; uint8_t* d_out = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_uv, n * 16));
+    HIPCHK(c, hipMalloc((void**)&d_out, n * 5));
+    HIPCHK(c, hipMemcpyAsync(d_uv, uv, n * 16, hipMemcpyHostToDevice, c->stream));
+    launch_selftest_sampler(c->stream, c->tex_dev, slot, d_uv, n, d_out);
+    HIPCHK(c, hipMemcpyAsync(out, d_out, n * 5, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d_uv)); HIPCHK(c, hipFree(d_out));
+    return TRGL_OK;
+}
+
 int trgl_set_stream(trgl_ctx* c, void* hip_stream, int use_own) {
     CHKCTX(c);
     if (c->rp.active) { int fr = trgl_flush_end(c); if (fr) return fr; }

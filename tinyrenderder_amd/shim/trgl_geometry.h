@@ -1,69 +1,93 @@
-// trgl_geometry.h — the value types a main.cpp-shaped caller needs (vec2/vec3/vec4, mat<R,C>),
-// with the reference's names and evaluation order (geometry.h:13-246) so host-side vertex stages
-// give bit-identical clip coordinates and varyings.  Written from scratch; only the interface
-// (names, member access, left-to-right summation from 0) follows the reference.
+// trgl_geometry.h — the small value types the shim and the demo caller use: vec2 / vec3 / vec4 and mat<R,C>.
+//
+// A maintainer who puts the library under the reference's main.cpp keeps the reference's own geometry.h: define
+// TRGL_GEOMETRY_HEADER to its path before including trgl_gl.h and this file is never seen.  It exists so that the
+// demo (examples/demo_main.cpp) and the tests build without the reference tree.  Only what the rasterize() path needs
+// is here, and what matters for bit-identical clip coordinates and varyings is kept: dot products are summed left to
+// right starting from 0.0, normalized() divides by the length, mat * vec is one dot product per row.
+//
+// Layout: every vec<N> is N packed doubles (vec<4>[3] is the 12-double `Triangle` memory image the C ABI takes), every
+// mat<R,C> is R*C packed doubles in row-major order.
 #pragma once
-#include <cassert>
 #include <cmath>
-#include <ostream>
+#include <cstddef>
 
-template <int n> struct vec {
-    double data[n] = {};
-    double& operator[](int i) { assert(i >= 0 && i < n); return data[i]; }
-    double operator[](int i) const { assert(i >= 0 && i < n); return data[i]; }
-};
-template <> struct vec<2> {
-    double x = 0, y = 0;
-    double& operator[](int i) { assert(i >= 0 && i < 2); return i ? y : x; }
-    double operator[](int i) const { assert(i >= 0 && i < 2); return i ? y : x; }
-};
-template <> struct vec<3> {
-    double x = 0, y = 0, z = 0;
-    double& operator[](int i) { assert(i >= 0 && i < 3); return i == 0 ? x : (i == 1 ? y : z); }
-    double operator[](int i) const { assert(i >= 0 && i < 3); return i == 0 ? x : (i == 1 ? y : z); }
-};
-template <> struct vec<4> {
-    double data[4] = { 0, 0, 0, 0 };
-    double& operator[](int i) { assert(i >= 0 && i < 4); return data[i]; }
-    double operator[](int i) const { assert(i >= 0 && i < 4); return data[i]; }
-    double x() const { return data[0]; }
-    double y() const { return data[1]; }
-    double z() const { return data[2]; }
-    double w() const { return data[3]; }
-    vec<2> xy() const { vec<2> r; r.x = data[0]; r.y = data[1]; return r; }
-    vec<3> xyz() const { vec<3> r; r.x = data[0]; r.y = data[1]; r.z = data[2]; return r; }
-};
-typedef vec<2> vec2;
-typedef vec<3> vec3;
-typedef vec<4> vec4;
+namespace trgl_math {
+// storage with named members for 2 and 3 components (callers write uv.x, n.z), plain arrays otherwise
+template <int N> struct store { double e[N]; };
+template <> struct store<2> { union { double e[2]; struct { double x, y; }; }; };
+template <> struct store<3> { union { double e[3]; struct { double x, y, z; }; }; };
+}  // namespace trgl_math
 
-template <int n> vec<n> operator+(const vec<n>& a, const vec<n>& b) { vec<n> r; for (int i = 0; i < n; ++i) r[i] = a[i] + b[i]; return r; }
-template <int n> vec<n> operator-(const vec<n>& a, const vec<n>& b) { vec<n> r; for (int i = 0; i < n; ++i) r[i] = a[i] - b[i]; return r; }
-template <int n> vec<n> operator*(const vec<n>& a, double s) { vec<n> r; for (int i = 0; i < n; ++i) r[i] = a[i] * s; return r; }
-template <int n> vec<n> operator*(double s, const vec<n>& a) { return a * s; }
-template <int n> vec<n> operator/(const vec<n>& a, double s) { vec<n> r; for (int i = 0; i < n; ++i) r[i] = a[i] / s; return r; }
-template <int n> vec<n> operator-(const vec<n>& a) { return a * -1.0; }
-template <int n> double dot(const vec<n>& a, const vec<n>& b) { double s = 0; for (int i = 0; i < n; ++i) s += a[i] * b[i]; return s; }
-template <int n> double norm(const vec<n>& a) { return std::sqrt(dot(a, a)); }
-inline vec3 normalized(const vec3& v) { double l = norm<3>(v); return l == 0 ? v : v / l; }
+template <int N> struct vec : trgl_math::store<N> {
+    vec() { for (int i = 0; i < N; ++i) this->e[i] = 0.0; }
+    double& operator[](int i) { return this->e[i]; }
+    const double& operator[](int i) const { return this->e[i]; }
+    // leading components as a shorter vector: v.xyz() of a vec4, v.xy() of a vec3 / vec4
+    vec<3> xyz() const { static_assert(N >= 3, "xyz() needs three components"); vec<3> r; r.e[0] = this->e[0]; r.e[1] = this->e[1]; r.e[2] = this->e[2]; return r; }
+    vec<2> xy() const { vec<2> r; r.e[0] = this->e[0]; r.e[1] = this->e[1]; return r; }
+};
+using vec2 = vec<2>;
+using vec3 = vec<3>;
+using vec4 = vec<4>;
+
+inline vec2 make_vec2(double a, double b) { vec2 r; r[0] = a; r[1] = b; return r; }
+inline vec3 make_vec3(double a, double b, double c) { vec3 r; r[0] = a; r[1] = b; r[2] = c; return r; }
+inline vec4 make_vec4(double a, double b, double c, double d) { vec4 r; r[0] = a; r[1] = b; r[2] = c; r[3] = d; return r; }
+
+// component-wise arithmetic through one helper
+namespace trgl_math {
+template <int N, class F> inline vec<N> zip(const vec<N>& a, const vec<N>& b, F f) { vec<N> r; for (int i = 0; i < N; ++i) r[i] = f(a[i], b[i]); return r; }
+template <int N, class F> inline vec<N> map(const vec<N>& a, F f) { vec<N> r; for (int i = 0; i < N; ++i) r[i] = f(a[i]); return r; }
+}  // namespace trgl_math
+template <int N> inline vec<N> operator+(const vec<N>& a, const vec<N>& b) { return trgl_math::zip(a, b, [](double p, double q) { return p + q; }); }
+template <int N> inline vec<N> operator-(const vec<N>& a, const vec<N>& b) { return trgl_math::zip(a, b, [](double p, double q) { return p - q; }); }
+template <int N> inline vec<N> operator*(const vec<N>& a, double s) { return trgl_math::map(a, [s](double p) { return p * s; }); }
+template <int N> inline vec<N> operator*(double s, const vec<N>& a) { return a * s; }
+template <int N> inline vec<N> operator/(const vec<N>& a, double s) { return trgl_math::map(a, [s](double p) { return p / s; }); }
+template <int N> inline vec<N> operator-(const vec<N>& a) { return a * -1.0; }
+
+// sum of products, left to right, starting from 0.0 (the accumulation order decides the low bits)
+template <int N> inline double dot(const vec<N>& a, const vec<N>& b) {
+    double acc = 0.0;
+    for (int i = 0; i < N; ++i) acc += a[i] * b[i];
+    return acc;
+}
+template <int N> inline double norm(const vec<N>& a) { return std::sqrt(dot(a, a)); }
+inline vec3 normalized(const vec3& a) {
+    const double len = norm(a);
+    if (len == 0.0) return a;
+    return a / len;
+}
 inline vec3 cross(const vec3& a, const vec3& b) {
-    vec3 r; r.x = a[1] * b[2] - a[2] * b[1]; r.y = a[2] * b[0] - a[0] * b[2]; r.z = a[0] * b[1] - a[1] * b[0]; return r;
+    return make_vec3(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
 }
-inline vec2 make_vec2(double x, double y) { vec2 r; r.x = x; r.y = y; return r; }
-inline vec3 make_vec3(double x, double y, double z) { vec3 r; r.x = x; r.y = y; r.z = z; return r; }
-inline vec4 make_vec4(double x, double y, double z, double w) { vec4 r; r[0] = x; r[1] = y; r[2] = z; r[3] = w; return r; }
 
+// R x C doubles, row-major; m[r] is the r-th row as a vec<C>
 template <int R, int C> struct mat {
-    vec<C> rows[R];
-    vec<C>& operator[](int r) { assert(r >= 0 && r < R); return rows[r]; }
-    const vec<C>& operator[](int r) const { assert(r >= 0 && r < R); return rows[r]; }
-    static mat identity() { mat m; for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) m[r][c] = (r == c) ? 1.0 : 0.0; return m; }
-    mat<C, R> transpose() const { mat<C, R> t; for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) t[c][r] = rows[r][c]; return t; }
+    vec<C> row[R];
+    vec<C>& operator[](int r) { return row[r]; }
+    const vec<C>& operator[](int r) const { return row[r]; }
+    static mat identity() {
+        mat m;
+        for (int i = 0; i < (R < C ? R : C); ++i) m.row[i][i] = 1.0;
+        return m;
+    }
 };
-template <int R, int C> vec<R> operator*(const mat<R, C>& m, const vec<C>& v) { vec<R> r; for (int i = 0; i < R; ++i) r[i] = dot<C>(m[i], v); return r; }
-template <int R1, int C1, int C2> mat<R1, C2> operator*(const mat<R1, C1>& a, const mat<C1, C2>& b) {
-    mat<R1, C2> r;
-    for (int i = 0; i < R1; ++i) for (int j = 0; j < C2; ++j) { r[i][j] = 0; for (int k = 0; k < C1; ++k) r[i][j] += a[i][k] * b[k][j]; }
-    return r;
+template <int R, int C> inline vec<R> operator*(const mat<R, C>& m, const vec<C>& v) {
+    vec<R> out;
+    for (int r = 0; r < R; ++r) out[r] = dot(m[r], v);
+    return out;
 }
-template <int n> std::ostream& operator<<(std::ostream& o, const vec<n>& v) { for (int i = 0; i < n; ++i) o << v[i] << " "; return o; }
+template <int R, int K, int C> inline mat<R, C> operator*(const mat<R, K>& a, const mat<K, C>& b) {
+    mat<R, C> out;
+    for (int r = 0; r < R; ++r)
+        for (int c = 0; c < C; ++c) {
+            double acc = 0.0;
+            for (int k = 0; k < K; ++k) acc += a[r][k] * b[k][c];
+            out[r][c] = acc;
+        }
+    return out;
+}
+static_assert(sizeof(vec<4>) == 4 * sizeof(double) && sizeof(vec<3>) == 3 * sizeof(double) && sizeof(vec<2>) == 2 * sizeof(double),
+              "vec<N> must be N packed doubles");

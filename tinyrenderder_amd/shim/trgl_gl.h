@@ -7,8 +7,12 @@
 // What changes for a caller, and why:
 //   * rasterize() is DEFERRED: it snapshots the clip coordinates, the shader's varyings and the uniforms that can
 //     change between calls (the global ModelView is read inside fragment(), main.cpp:116) and batches them; the GPU
-//     runs them in submission order at gl_flush().  Call gl_flush(framebuffer) before touching `zbuffer` or the
-//     framebuffer's pixels (the reference does so at main.cpp:700,730,743,751,759,773).
+//     runs them in submission order.  `zbuffer` is a proxy whose accessors complete the pending work first, so the
+//     reference's direct uses of it (main.cpp:700,730,751,759) need no edit; the framebuffer is the caller's own TGAImage,
+//     so gl_flush(framebuffer) goes before the places that read its pixels (main.cpp:743,773).
+//   * gl_draw_model(model, shader, framebuffer) replaces a whole face loop (main.cpp:660-666,692-698,715-721): the
+//     vertex stage runs on the device from Model::vertices / indices (trgl_draw_indexed), 112 B per vertex + 12 B per face
+//     cross PCIe instead of 288 + 96 B per face.
 //   * a C++ virtual cannot be called from a kernel: IShader gains describe(), returning the POD descriptor of a
 //     shader kind the device implements (trgl_shaders.h: FlatShader, GouraudShader, PhongShader, EyeShader).
 //     A subclass without one makes rasterize() fail loudly — there is NO CPU fallback.
@@ -17,12 +21,24 @@
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
+#include <cstring>
+
 #include "../../include/trgl.h"
+// the caller's own value types (the reference's geometry.h) or the repo's minimal ones
+#ifdef TRGL_GEOMETRY_HEADER
+#include TRGL_GEOMETRY_HEADER
+#else
 #include "trgl_geometry.h"
+#endif
+#ifdef TRGL_IMAGE_HEADER
+#include TRGL_IMAGE_HEADER
+#else
 #include "trgl_image.h"
+#endif
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -31,7 +47,32 @@
 inline mat<4, 4> ModelView = mat<4, 4>::identity();
 inline mat<4, 4> Perspective = mat<4, 4>::identity();
 inline mat<4, 4> Viewport = mat<4, 4>::identity();
-inline std::vector<double> zbuffer;
+
+// The reference's global `std::vector<double> zbuffer` (our_gl.h:20) with the depths living in HBM: every accessor first
+// completes what rasterize() has batched and brings the depths to the host copy; anything that can modify the host copy
+// marks it, and the next draw uploads it.  `std::vector<double> saved = zbuffer;` (main.cpp:700), `zbuffer = saved;`
+// (main.cpp:730), `zbuffer[idx]`, `zbuffer.size()` and passing it as `const std::vector<double>&` (main.cpp:751,759)
+// compile and behave as with the vector.
+class trgl_zbuffer_proxy {
+    std::vector<double> host_;
+    void pull() const;                       // pending draws -> device -> host_
+    void touched();                          // the caller may have written host_
+public:
+    operator const std::vector<double>&() const { pull(); return host_; }
+    trgl_zbuffer_proxy& operator=(const std::vector<double>& v) { pull(); host_ = v; touched(); return *this; }
+    double operator[](std::size_t i) const { pull(); return host_[i]; }
+    double& operator[](std::size_t i) { pull(); touched(); return host_[i]; }
+    std::size_t size() const { return host_.size(); }
+    bool empty() const { return host_.empty(); }
+    const double* data() const { pull(); return host_.data(); }
+    double* data() { pull(); touched(); return host_.data(); }
+    std::vector<double>::const_iterator begin() const { pull(); return host_.begin(); }
+    std::vector<double>::const_iterator end() const { return host_.end(); }
+    void assign(std::size_t n, double v);    // init_zbuffer (our_gl.cpp:72-74)
+    void resize(std::size_t n) { host_.resize(n); }
+    std::vector<double>& raw() { return host_; }   // the shim's own access: no synchronisation
+};
+inline trgl_zbuffer_proxy zbuffer;
 
 // What a shader hands to the device: kind + uniforms + this triangle's varyings/colour (include/trgl.h).
 struct trgl_shader_desc {
@@ -65,6 +106,7 @@ struct State {
     trgl_ctx* ctx = nullptr;
     int w = 0, h = 0, bpp = 0;
     bool zbuffer_dirty_on_host = false;   // init_zbuffer()/host writes not yet on the device
+    bool zbuffer_stale_on_host = false;   // the device drew since the host copy was fetched
     bool have_batch = false;
     int kind = 0;
     trgl_uniforms uniforms{};
@@ -93,9 +135,11 @@ inline void bind(TGAImage& fb) {
         s.zbuffer_dirty_on_host = true;
     }
     if (s.zbuffer_dirty_on_host) {
-        if (zbuffer.size() != std::size_t(s.w) * s.h) zbuffer.assign(std::size_t(s.w) * s.h, std::numeric_limits<double>::infinity());
-        TRGL_SHIM_CHK(trgl_write_zbuffer(s.ctx, zbuffer.data()));
+        std::vector<double>& hz = zbuffer.raw();
+        if (hz.size() != std::size_t(s.w) * s.h) hz.assign(std::size_t(s.w) * s.h, std::numeric_limits<double>::infinity());
+        TRGL_SHIM_CHK(trgl_write_zbuffer(s.ctx, hz.data()));
         s.zbuffer_dirty_on_host = false;
+        s.zbuffer_stale_on_host = false;
     }
 }
 
@@ -109,6 +153,7 @@ inline void submit_batch() {
                             s.colors.data(), s.clip.size() / 12, TRGL_MEM_HOST));
     s.clip.clear(); s.vary.clear(); s.colors.clear();
     s.have_batch = false;
+    s.zbuffer_stale_on_host = true;
 }
 
 inline int vary_count(int kind) {
@@ -142,14 +187,33 @@ inline void init_viewport(int x, int y, int w, int h) {                         
     Viewport[2][2] = 1.0; Viewport[2][3] = 0.0;
 }
 inline void init_zbuffer(int width, int height) {                                 // our_gl.cpp:72-74
-    trgl_shim::State& s = trgl_shim::state();
-    if (s.ctx) { trgl_shim::submit_batch(); TRGL_SHIM_CHK(trgl_flush(s.ctx)); }
     zbuffer.assign(std::size_t(width) * height, std::numeric_limits<double>::infinity());
-    s.zbuffer_dirty_on_host = true;
 }
 
-// Tell the shim the host changed `zbuffer` (main.cpp:730 restores a saved copy) or the framebuffer's pixels.
-inline void gl_zbuffer_modified() { trgl_shim::state().zbuffer_dirty_on_host = true; }
+inline void trgl_zbuffer_proxy::pull() const {
+    trgl_shim::State& s = trgl_shim::state();
+    if (!s.ctx) return;
+    trgl_shim::submit_batch();                                  // triangles batched so far are drawn against the depths as they are now
+    if (!s.zbuffer_stale_on_host || s.zbuffer_dirty_on_host) return;
+    std::vector<double>& hz = const_cast<std::vector<double>&>(host_);
+    hz.resize(std::size_t(s.w) * s.h);
+    TRGL_SHIM_CHK(trgl_read_zbuffer(s.ctx, hz.data()));
+    s.zbuffer_stale_on_host = false;
+}
+inline void trgl_zbuffer_proxy::touched() { trgl_shim::state().zbuffer_dirty_on_host = true; }
+inline void trgl_zbuffer_proxy::assign(std::size_t n, double v) {
+    trgl_shim::State& s = trgl_shim::state();
+    if (s.ctx) { trgl_shim::submit_batch(); TRGL_SHIM_CHK(trgl_flush(s.ctx)); }   // earlier draws see the old depths
+    host_.assign(n, v);
+    s.zbuffer_dirty_on_host = true; s.zbuffer_stale_on_host = false;
+}
+
+// Tell the shim the host changed the depths behind the proxy's back (through zbuffer.raw()) or the framebuffer's pixels.
+inline void gl_zbuffer_modified() {
+    trgl_shim::State& s = trgl_shim::state();
+    if (s.ctx) { trgl_shim::submit_batch(); TRGL_SHIM_CHK(trgl_flush(s.ctx)); }   // what was batched was drawn against the OLD depths
+    s.zbuffer_dirty_on_host = true;
+}
 inline void gl_framebuffer_modified(TGAImage& fb) {
     trgl_shim::State& s = trgl_shim::state();
     if (s.ctx) { trgl_shim::submit_batch(); TRGL_SHIM_CHK(trgl_write_framebuffer(s.ctx, fb.buffer())); }
@@ -178,22 +242,55 @@ inline void rasterize(const Triangle& clip, const IShader& shader, TGAImage& fra
                          !same_matrix(s.viewport_at_batch, Viewport)))
         submit_batch();
     if (!s.have_batch) { s.have_batch = true; s.kind = d.kind; s.uniforms = d.uniforms; s.viewport_at_batch = Viewport; }
-    for (int v = 0; v < 3; ++v) for (int c = 0; c < 4; ++c) s.clip.push_back(clip[v][c]);
-    for (int k = 0; k < K; ++k) s.vary.push_back(d.varyings[k]);
+    static_assert(sizeof(Triangle) == 12 * sizeof(double), "Triangle must be 12 packed doubles");
+    const double* cp = &clip[0][0];
+    s.clip.insert(s.clip.end(), cp, cp + 12);                   // the Triangle memory image (our_gl.h:55)
+    if (K) s.vary.insert(s.vary.end(), d.varyings, d.varyings + K);
     s.colors.push_back(d.color);
     if (s.clip.size() >= std::size_t(12) << 20) submit_batch();      // bound host memory: 1 Mi triangles per batch
 }
 
-// Run everything submitted so far and bring framebuffer + zbuffer back to the host objects the reference's
-// callers read directly.
+// A whole face loop in one call (main.cpp:660-666, 692-698, 715-721):
+//     for face: for v in 0..2: clip[v] = shader.vertex(face, v);  rasterize(clip, shader, framebuffer);
+// The shader's describe() supplies kind + uniforms (ModelView at call time, lights, texture slots); the vertex stage
+// (main.cpp:71-90 = 199-218: eye = ModelView*(p,1), normal_eye = ModelView*(n,0), clip = Perspective*eye) runs on the
+// device over the indexed mesh.  `vertices`: nv rows of `stride` doubles starting with position[3], normal[3], uv[2]
+// (the reference's Vertex, model.h:14-20, has stride 14); `indices`: 3 per face.
+inline void gl_draw_indexed(const IShader& shader, const double* vertices, int stride, std::size_t nv,
+                            const unsigned int* indices, std::size_t nfaces, TGAImage& framebuffer) {
+    using namespace trgl_shim;
+    State& s = state();
+    bind(framebuffer);
+    submit_batch();                                             // earlier rasterize() calls come first
+    trgl_shader_desc d;
+    if (!shader.describe(d) || (d.kind != TRGL_SHADER_PHONG && d.kind != TRGL_SHADER_EYE)) {
+        std::fprintf(stderr, "trgl: gl_draw_indexed(): needs a PHONG or EYE shader with a device descriptor\n");
+        std::abort();
+    }
+    double vp[16], pj[16];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { vp[4 * r + c] = Viewport[r][c]; pj[4 * r + c] = Perspective[r][c]; }
+    TRGL_SHIM_CHK(trgl_set_viewport(s.ctx, vp));
+    static_assert(sizeof(unsigned int) == sizeof(std::uint32_t), "indices are 32-bit");
+    TRGL_SHIM_CHK(trgl_draw_indexed(s.ctx, d.kind, &d.uniforms, pj, vertices, stride, nv,
+                                    reinterpret_cast<const std::uint32_t*>(indices), nfaces, TRGL_MEM_HOST));
+    s.zbuffer_stale_on_host = true;
+}
+// ... for a model that keeps `vertices` (records of packed doubles) and `indices` as the reference's Model does (model.h:114-115)
+template <class ModelT> inline void gl_draw_model(const ModelT& model, const IShader& shader, TGAImage& framebuffer) {
+    using V = typename std::decay<decltype(model.vertices[0])>::type;
+    static_assert(sizeof(V) % sizeof(double) == 0, "vertex records must be packed doubles");
+    gl_draw_indexed(shader, reinterpret_cast<const double*>(model.vertices.data()), int(sizeof(V) / sizeof(double)),
+                    model.vertices.size(), model.indices.data(), model.indices.size() / 3, framebuffer);
+}
+
+// Run everything submitted so far and bring the pixels back into the caller's TGAImage (before framebuffer.get(),
+// write_tga_file(), main.cpp:743,773).  The depths follow on demand through the `zbuffer` proxy.
 inline void gl_flush(TGAImage& framebuffer) {
     using namespace trgl_shim;
     State& s = state();
     bind(framebuffer);
     submit_batch();
     TRGL_SHIM_CHK(trgl_read_framebuffer(s.ctx, framebuffer.buffer()));
-    zbuffer.resize(std::size_t(s.w) * s.h);
-    TRGL_SHIM_CHK(trgl_read_zbuffer(s.ctx, zbuffer.data()));
 }
 
 // main.cpp:751-785 on the device (z-buffer never leaves HBM): fills the three images the reference writes as
