@@ -121,6 +121,9 @@ def main():
                          "that the k_raster statistics hold the full launches only)")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (profiling runs)")
     ap.add_argument("--end-to-end-frames", type=int, default=2, help="PCIe-inclusive frames timed after the run (0 = skip)")
+    ap.add_argument("--partition", default="strips", choices=["strips", "bands"],
+                    help="N > 1: one horizontal strip per rank (default), or bands of --band-rows rows dealt round-robin (load-balanced)")
+    ap.add_argument("--band-rows", type=int, default=128)
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL strip-gather path even with one rank (rehearsal)")
     ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3"],
                     help="c4 (default, the metric's config): 10 M random flat triangles; c2/c3: PHONG head stand-in at 2048/4096")
@@ -174,7 +177,10 @@ def main():
     y0, y1 = shard.strip_rows(H, world, rank)
     full_fb = None
     if use_dist:
-        ctx.set_strip(y0, y1)
+        if args.partition == "bands":
+            ctx.set_interleave(args.band_rows, rank, world)
+        else:
+            ctx.set_strip(y0, y1)
         full_fb = shard.framebuffer_tensor(ctx)
 
     def submit(c):
@@ -184,7 +190,11 @@ def main():
     # N > 1: join the colour strips so that every rank ends with the whole TGAImage buffer.  The gather runs on RCCL's stream;
     # only the raster half of the NEXT frame touches the framebuffer, so that frame's setup and binning run under it
     # (shard.StripLoop; tests/test_gpu_parity.py drives the same loop with two contexts on one GPU).
-    loop = shard.StripLoop(ctx, lambda: shard.gather_strips(full_fb, W, H, 3, rank, world, async_op=True)) if use_dist else None
+    if args.partition == "bands":
+        start_gather = lambda: shard.gather_bands(full_fb, W, H, 3, args.band_rows, rank, world, async_op=True)
+    else:
+        start_gather = lambda: shard.gather_strips(full_fb, W, H, 3, rank, world, async_op=True)
+    loop = shard.StripLoop(ctx, start_gather) if use_dist else None
 
     def step():
         if loop is None:
@@ -292,7 +302,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl_name,
                        "width": W, "height": H, "triangles": N, "tile": 32,
-                       "parallelism": f"screen strips x{world}" + (" + RCCL all-gather of colour strips" if world > 1 else "")},
+                       "parallelism": (f"screen strips x{world}" if args.partition == "strips" else f"interleaved {args.band_rows}-row bands x{world}")
+                                      + (" + RCCL all-gather of colour strips" if world > 1 else "")},
             "parity": parity,
             "mpixels_per_s": W * H * args.steps / elapsed / 1e6,
             "tri_tile_pairs": info["pairs"],

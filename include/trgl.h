@@ -136,6 +136,13 @@ int trgl_upload_texture(trgl_ctx* ctx, int slot, const uint8_t* texels, int w, i
  * are still all counted/bboxed (setup is replicated), pixels outside the strip are not touched. */
 int trgl_set_strip(trgl_ctx* ctx, int y0, int y1);
 
+/* Multi-GPU, load-balanced alternative to one strip: the image is cut into bands of `band_rows` rows (a multiple of 32) that
+ * are dealt round-robin to `world` contexts; this one takes the bands whose number is `rank` modulo `world`.  A mesh that sits
+ * in the middle rows then loads every rank alike.  Within each period of world * band_rows rows the bands lie in rank order, so
+ * one in-place all-gather per period joins them (tinyrenderder_amd/shard.py: gather_bands).  world = 1 or trgl_set_strip()
+ * returns to a single strip. */
+int trgl_set_interleave(trgl_ctx* ctx, int band_rows, int rank, int world);
+
 /* ---- submission ---------------------------------------------------------------------------- */
 
 /* Replaces: n consecutive calls of rasterize(clip, shader, framebuffer) (our_gl.h:58,

@@ -611,3 +611,34 @@ def test_device_sampler_equals_reference_sample2d(i):
     bad = np.argwhere((got != want).any(axis=1))
     assert bad.size == 0, f"{len(bad)} samples differ, first uv {uv[bad[0, 0]]}: {got[bad[0, 0]]} vs {want[bad[0, 0]]}"
     assert (empty == np.array([255, 255, 255, 255, 4], np.uint8)).all()
+
+
+@pytest.mark.parametrize("name,world,band", [("flat_persp_512", 4, 32), ("flat_persp_512", 2, 128), ("phong_512", 4, 64), ("multi_draw_320x200", 1, 32)])
+def test_interleaved_bands_compose(name, world, band):
+    """trgl_set_interleave: bands of `band` rows dealt round-robin to `world` contexts (the load-balanced alternative to one
+    strip per rank).  Every context's own bands equal the rows of the unsharded frame (colours and depths; PHONG goes through
+    the visibility buffer + k_shade), the fragment counts add up and the z range is the min / max over ranks."""
+    from tinyrenderder_amd import shard
+    case = cases.CASES[name]()
+    W, H = case["width"], case["height"]
+    fb, z, st, _ = cases.run_gpu(case)
+    frags, zmin, zmax = 0, np.inf, -np.inf
+    for rank in range(world):
+        with Context(W, H, case["bpp"]) as ctx:
+            ctx.set_viewport(case["viewport"]); ctx.clear(case["clear"], case["zclear"])
+            ctx.set_interleave(band, rank, world)
+            for slot, t in case["textures"].items():
+                ctx.upload_texture(slot, t)
+            for kind, u, clip, vary, col in case["draws"]:
+                ctx.draw(kind, clip, vary, col, u)
+            rfb, rz, rst = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+        rows = shard.band_rows_of(H, world, rank, band) if world > 1 else [(0, H)]
+        for y0, y1 in rows:
+            if name in POW_CASES:
+                _assert_fb(rfb[y0:y1], fb[y0:y1], name)
+            else:
+                assert np.array_equal(rfb[y0:y1], fb[y0:y1]), f"rank {rank}: colours of rows {y0}..{y1}"
+            assert np.array_equal(rz[y0:y1].view(np.uint64), z[y0:y1].view(np.uint64)), f"rank {rank}: depths of rows {y0}..{y1}"
+        assert rst[0] == st[0] and rst[2:6] == st[2:6]
+        frags += rst[1]; zmin = min(zmin, rst[6]); zmax = max(zmax, rst[7])
+    assert (frags, zmin, zmax) == (st[1], st[6], st[7])

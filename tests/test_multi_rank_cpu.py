@@ -46,6 +46,43 @@ def test_two_ranks_gloo_strips_equal_whole_frame(name):
         assert rst == st
 
 
+def _band_worker(rank, world, port, band, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        case = cases.CASES["flat_persp_512"]()
+        W, H, bpp = case["width"], case["height"], case["bpp"]
+        fb, z, _ = cases.run_oracle(case)
+        own = np.zeros(H, bool)
+        for y0, y1 in shard.band_rows_of(H, world, rank, band):
+            own[y0:y1] = True
+        fb[~own] = 0xAA                                          # rows of other ranks hold garbage before the gather
+        zb = z.view(np.uint8).reshape(H, W * 8).copy(); zb[~own] = 0xAA
+        full = torch.from_numpy(fb.reshape(-1))
+        shard.gather_bands(full, W, H, bpp, band, rank, world)
+        zfull = torch.from_numpy(zb.reshape(-1))
+        work = shard.gather_bands(zfull, W, H, 8, band, rank, world, async_op=True)       # the asynchronous form bench.py uses
+        work.wait()
+        ret[rank] = (full.numpy().reshape(H, W, bpp).copy(), zfull.numpy().view(np.float64).reshape(H, W).copy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,band", [(2, 64), (4, 32), (4, 128)])
+def test_interleaved_bands_gather_gloo(world, band):
+    """shard.gather_bands: one in-place all-gather per period of world * band rows joins interleaved bands (world 2 and 4)."""
+    port = 31500 + (os.getpid() % 2000) + world
+    ret = mp.Manager().dict()
+    mp.spawn(_band_worker, args=(world, port, band, ret), nprocs=world, join=True)
+    fb, z, _ = cases.run_oracle(cases.CASES["flat_persp_512"]())
+    for rank in range(world):
+        rfb, rz = ret[rank]
+        assert np.array_equal(rfb, fb), f"rank {rank}: gathered framebuffer differs"
+        assert np.array_equal(rz.view(np.uint64), z.view(np.uint64))
+    with pytest.raises(ValueError):
+        shard.band_rows_of(500, 4, 0, 32)
+
+
 def test_strip_rows_partition():
     for H, G in ((4096, 8), (8192, 8), (512, 2), (96, 3)):
         edges = [shard.strip_rows(H, G, r) for r in range(G)]

@@ -24,7 +24,7 @@ MAX_TEXTURES = 16
 # every symbol include/trgl.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "trgl_create", "trgl_destroy", "trgl_last_error", "trgl_set_viewport", "trgl_init_viewport", "trgl_clear",
-    "trgl_upload_texture", "trgl_set_strip", "trgl_draw", "trgl_flush", "trgl_flush_begin", "trgl_flush_end", "trgl_sync", "trgl_read_framebuffer",
+    "trgl_upload_texture", "trgl_set_strip", "trgl_set_interleave", "trgl_draw", "trgl_flush", "trgl_flush_begin", "trgl_flush_end", "trgl_sync", "trgl_read_framebuffer",
     "trgl_write_framebuffer", "trgl_read_zbuffer", "trgl_write_zbuffer", "trgl_get_stats", "trgl_reset_stats",
     "trgl_format_stats", "trgl_framebuffer_device_ptr", "trgl_zbuffer_device_ptr", "trgl_stream", "trgl_set_stream",
     "trgl_set_profiling", "trgl_get_phase_ms", "trgl_reset_phase_ms", "trgl_get_last_flush_info",
@@ -108,6 +108,7 @@ def load_library(path: str = None):
     L.trgl_clear.argtypes = [vp, C.c_void_p, C.c_double]
     L.trgl_upload_texture.argtypes = [vp, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.trgl_set_strip.argtypes = [vp, C.c_int, C.c_int]
+    L.trgl_set_interleave.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.trgl_draw.argtypes = [vp, C.c_int, C.POINTER(Uniforms), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
     L.trgl_flush.argtypes = [vp]
     L.trgl_flush_begin.argtypes = [vp]
@@ -261,6 +262,10 @@ class Context:
 
     def set_strip(self, y0, y1):
         self._chk(self.L.trgl_set_strip(self.h, y0, y1))
+
+    def set_interleave(self, band_rows, rank, world):
+        """Own the bands of `band_rows` rows whose number is `rank` modulo `world` (instead of one strip)."""
+        self._chk(self.L.trgl_set_interleave(self.h, band_rows, rank, world))
 
     # ---- submission ----
     def draw(self, kind, clip, varyings=None, colors=None, uniforms=None, n=None, device=False):

@@ -140,7 +140,10 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
             if (!(fabs(r.uz) < 1e-12) && y_lo <= y_hi) {
                 uint32_t tx0 = bx0 >> TRGL_TILE_LOG2, tx1 = bx1 >> TRGL_TILE_LOG2;
                 uint32_t ty0 = y_lo >> TRGL_TILE_LOG2, ty1 = y_hi >> TRGL_TILE_LOG2;
-                ntiles = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+                // tile rows of the box that this context owns: all of them for a strip (the box is clipped to it), the ones of
+                // its bands with interleaved ownership (k_expand walks the same rows)
+                const uint32_t rows = fp.il_tiles ? (uint32_t)(il_owned_below(fp, (int)ty1 + 1) - il_owned_below(fp, (int)ty0)) : ty1 - ty0 + 1;
+                ntiles = (tx1 - tx0 + 1) * rows;
                 tb = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
             }
         }
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chunk_spine(const uint32_t* __
 
 // expand: triangle i owns pairs [off, off + cnt[i]) = its tiles in row-major order; off is computed here.
 // Triangles with many tiles are written by the whole wave.  One launch per draw (same blocks as k_setup).
-__global__ __launch_bounds__(256) void k_expand(uint32_t first, uint32_t n, int tiles_x, const uint32_t* __restrict__ cnt,
+__global__ __launch_bounds__(256) void k_expand(FrameParams fp, uint32_t first, uint32_t n, int tiles_x, const uint32_t* __restrict__ cnt,
                                                 const uint32_t* __restrict__ blk_sums, const uint32_t* __restrict__ chunk_off,
                                                 uint32_t blk_base, const uint2* __restrict__ tilebox,
                                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256) void k_expand(uint32_t first, uint32_t n, int 
         uint32_t tx0 = tb.x & 0xffff, ty0 = tb.x >> 16, tx1 = tb.y & 0xffff;
         uint32_t wdt = tx1 - tx0 + 1;
         for (uint32_t k = 0; k < c; ++k) {
-            uint32_t ty = ty0 + k / wdt, tx = tx0 + k % wdt;
+            uint32_t ty = fp.il_tiles ? (uint32_t)il_nth_owned_from(fp, (int)ty0, (int)(k / wdt)) : ty0 + k / wdt, tx = tx0 + k % wdt;
             keys[o + k] = ty * tiles_x + tx; vals[o + k] = i;
         }
     }
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256) void k_expand(uint32_t first, uint32_t n, int 
         uint32_t tx0 = bx & 0xffff, ty0 = bx >> 16, tx1 = by & 0xffff;
         uint32_t wdt = tx1 - tx0 + 1;
         for (uint32_t k = lane; k < cc; k += 64) {
-            uint32_t ty = ty0 + k / wdt, tx = tx0 + k % wdt;
+            uint32_t ty = fp.il_tiles ? (uint32_t)il_nth_owned_from(fp, (int)ty0, (int)(k / wdt)) : ty0 + k / wdt, tx = tx0 + k % wdt;
             keys[oo + k] = ty * tiles_x + tx; vals[oo + k] = ii;
         }
     }
@@ -527,11 +530,11 @@ void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uin
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, block_sums, out);
 }
 
-void launch_expand(hipStream_t s, uint32_t first, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* blk_sums,
+void launch_expand(hipStream_t s, const FrameParams& fp, uint32_t first, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* blk_sums,
                    const uint32_t* chunk_off, uint32_t blk_base, const uint2* tilebox, uint32_t* keys, uint32_t* vals,
                    const unsigned long long* pairs_total, uint32_t cap) {
     if (!n) return;
-    hipLaunchKernelGGL(k_expand, dim3(setup_num_blocks(n)), dim3(SETUP_THREADS), 0, s, first, n, tiles_x, cnt, blk_sums, chunk_off,
+    hipLaunchKernelGGL(k_expand, dim3(setup_num_blocks(n)), dim3(SETUP_THREADS), 0, s, fp, first, n, tiles_x, cnt, blk_sums, chunk_off,
                        blk_base, tilebox, keys, vals, pairs_total, cap);
 }
 

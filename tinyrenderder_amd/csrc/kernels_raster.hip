@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256) void k_make_items(FrameParams fp, const uint32
     if (k < ntiles_strip) {
         t = (uint32_t)(fp.strip_ty0 * fp.tiles_x + k);
         const uint32_t n = tile_end[t] - tile_start[t];
-        if (n || fp.init_from_clear) {
+        if ((n || fp.init_from_clear) && tile_row_owned(fp, (int)(t / (uint32_t)fp.tiles_x))) {
             while (bl < 4 && (n >> bl) > split_len) ++bl;      // 1, 2, 4, 8 or 16 bands
             nb = 1u << bl;
         }
@@ -1022,8 +1022,13 @@ void launch_selftest_sampler(hipStream_t s, const DevTexture* tex, int slot, con
     if (n) hipLaunchKernelGGL(k_selftest_sampler, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tex, slot, uv, n, out);
 }
 
+uint32_t owned_tiles(const FrameParams& fp) {
+    if (fp.il_tiles == 0) return (uint32_t)((fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x);
+    return (uint32_t)(il_owned_below(fp, fp.tiles_y) * fp.tiles_x);
+}
+
 uint32_t raster_max_items(const FrameParams& fp, uint64_t pairs, uint32_t split_len) {
-    const uint64_t tiles = (uint64_t)(fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x;
+    const uint64_t tiles = owned_tiles(fp);
     // a tile with n entries makes at most max(1, 2n/split_len) bands (<= 16)
     uint64_t extra = split_len ? 2 * pairs / split_len : 0;
     if (extra > tiles * 15) extra = tiles * 15;

@@ -17,7 +17,7 @@ void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uin
 
 // expand / radix / bounds read the flush's pair count from device memory and cover `cap` (the capacity of the pair buffers)
 // with their grids; they do nothing when the count exceeds it (the host then grows the buffers and queues them again)
-void launch_expand(hipStream_t s, uint32_t first, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* blk_sums,
+void launch_expand(hipStream_t s, const FrameParams& fp, uint32_t first, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* blk_sums,
                    const uint32_t* chunk_off, uint32_t blk_base, const uint2* tilebox, uint32_t* keys, uint32_t* vals,
                    const unsigned long long* pairs_total, uint32_t cap);
 
@@ -29,6 +29,7 @@ void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* v
 void launch_bounds(hipStream_t s, const uint32_t* keys, const unsigned long long* pairs_total, uint32_t cap,
                    uint32_t* tile_start, uint32_t* tile_end);
 
+uint32_t owned_tiles(const FrameParams& fp);       // tiles of the rows this context owns (strip or interleaved bands)
 uint32_t raster_max_items(const FrameParams& fp, uint64_t pairs, uint32_t split_len);
 void launch_raster(hipStream_t s, const FrameParams& fp, int kind, const TriRec* recs, const uint32_t* vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -39,6 +40,7 @@ struct trgl_ctx {
     uint32_t clear_color = 0xff000000u;
     double clear_z = std::numeric_limits<double>::infinity();
     int strip_y0 = 0, strip_y1 = 0;
+    int il_tiles = 0, il_world = 1, il_rank = 0;     // interleaved bands instead of one strip (trgl_set_interleave)
 
     DevTexture tex_host[TRGL_MAX_TEXTURES];
     DevTexture* tex_dev = nullptr;
@@ -250,6 +252,18 @@ int trgl_set_strip(trgl_ctx* c, int y0, int y1) {
     if (y0 < 0 || y1 > c->H || y0 > y1) return fail(c, TRGL_E_INVALID, "trgl_set_strip: need 0 <= y0 <= y1 <= H");
     if (!c->draws.empty()) { int r = trgl_flush(c); if (r) return r; }
     c->strip_y0 = y0; c->strip_y1 = y1;
+    c->il_tiles = 0; c->il_world = 1; c->il_rank = 0;
+    return TRGL_OK;
+}
+
+int trgl_set_interleave(trgl_ctx* c, int band_rows, int rank, int world) {
+    CHKCTX(c);
+    if (c->rp.active) { int fr = trgl_flush_end(c); if (fr) return fr; }
+    if (band_rows <= 0 || band_rows % TRGL_TILE || world < 1 || rank < 0 || rank >= world)
+        return fail(c, TRGL_E_INVALID, "trgl_set_interleave: band_rows must be a positive multiple of 32, 0 <= rank < world");
+    if (!c->draws.empty()) { int r = trgl_flush(c); if (r) return r; }
+    c->strip_y0 = 0; c->strip_y1 = c->H;
+    c->il_tiles = world > 1 ? band_rows / TRGL_TILE : 0; c->il_world = world; c->il_rank = rank;
     return TRGL_OK;
 }
 
@@ -418,14 +432,14 @@ int trgl_flush(trgl_ctx* c) {
 
 // expand -> stable radix passes by tile id -> per-tile bounds, for pair buffers of capacity `cap`.  All of it reads the pair
 // count from device memory; when the count exceeds `cap` every kernel here does nothing.
-static int queue_binning(trgl_ctx* c, uint32_t cap, int* cur_out) {
+static int queue_binning(trgl_ctx* c, const FrameParams& fp, uint32_t cap, int* cur_out) {
     hipStream_t s = c->stream;
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
     const unsigned long long* pairs_dev = &c->stats_dev->pairs_total;
     int r;
     uint32_t blk_base = 0;
     for (auto& d : c->draws) {
-        launch_expand(s, d.first, d.n, c->tiles_x, c->cnt, c->blk_sums, c->chunk_off, blk_base, c->tilebox, c->keys[0], c->vals[0], pairs_dev, cap);
+        launch_expand(s, fp, d.first, d.n, c->tiles_x, c->cnt, c->blk_sums, c->chunk_off, blk_base, c->tilebox, c->keys[0], c->vals[0], pairs_dev, cap);
         blk_base += setup_num_blocks(d.n);
     }
     int key_bits = 1; while ((size_t(1) << key_bits) < ntiles) ++key_bits;
@@ -481,6 +495,7 @@ int trgl_flush_begin(trgl_ctx* c) {
     fp.strip_ty0 = c->strip_y0 / TRGL_TILE;
     fp.strip_ty1 = (c->strip_y1 + TRGL_TILE - 1) / TRGL_TILE;
     if (c->strip_y1 <= c->strip_y0) fp.strip_ty1 = fp.strip_ty0;
+    fp.il_tiles = c->il_tiles; fp.il_world = c->il_world; fp.il_rank = c->il_rank;
     fp.init_from_clear = c->clear_pending ? 1 : 0;
     fp.clear_color = c->clear_color; fp.clear_z = c->clear_z;
     std::memcpy(fp.vp, c->vp, sizeof(fp.vp));
@@ -526,7 +541,7 @@ int trgl_flush_begin(trgl_ctx* c) {
         HIPCHK(c, hipEventRecord(c->ev_pairs, s));
         HIPCHK(c, hipMemsetAsync(c->tile_start, 0, ntiles * 8, s));                // tile_start and tile_end
         cap = (uint32_t)c->cap_pairs;
-        if ((r = queue_binning(c, cap, &cur))) return r;
+        if ((r = queue_binning(c, fp, cap, &cur))) return r;
     } else {
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
         HIPCHK(c, hipMemsetAsync(c->tile_start, 0, ntiles * 8, s));
@@ -559,7 +574,7 @@ int trgl_flush_end(trgl_ctx* c) {
         P = (uint32_t)P64;
         if (P > c->rp.cap) {                               // the buffers were too small: the queued binning did nothing
             if ((r = grow_pairs(c, P))) return r;
-            if ((r = queue_binning(c, (uint32_t)c->cap_pairs, &cur))) return r;
+            if ((r = queue_binning(c, fp, (uint32_t)c->cap_pairs, &cur))) return r;
             if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], s));
         }
     }
@@ -570,7 +585,7 @@ int trgl_flush_end(trgl_ctx* c) {
     // A lone wave needs ~1-3 us per list entry (one long dependent fp64 chain); throughput comes from many waves.
     // So lists longer than twice the mean list length (at least 8 entries) are cut into 2..16 row bands: dense
     // uniform scenes (C4: 1100 entries in every tile) never split, sparse or uneven ones (meshes) get parallelism.
-    const uint64_t strip_tiles = (uint64_t)(fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x;
+    const uint64_t strip_tiles = owned_tiles(fp);
     uint32_t split_len = 8;
     if (strip_tiles && 2 * (uint64_t)P / strip_tiles > split_len) split_len = (uint32_t)(2 * (uint64_t)P / strip_tiles);
     // ... unless the strip has fewer tiles than the GPU has wave slots (a rank of a multi-GPU run, a small frame): then
@@ -687,7 +702,11 @@ void* trgl_stream(trgl_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int trgl_obj_load(const char* path, double** vertices, uint64_t* n_vertices, uint32_t** indices, uint64_t* n_faces) {
     if (!path || !vertices || !n_vertices || !indices || !n_faces) return TRGL_E_INVALID;
     trgl_obj::Mesh m;
-    if (!trgl_obj::load(path, m)) { g_create_error = m.error; return TRGL_E_INVALID; }
+    try {
+        if (!trgl_obj::load(path, m)) { g_create_error = m.error; return TRGL_E_INVALID; }
+    } catch (const std::bad_alloc&) {
+        g_create_error = "trgl_obj_load: out of memory"; return TRGL_E_NOMEM;
+    }
     *n_vertices = m.vertices.size() / 14; *n_faces = m.indices.size() / 3;
     *vertices = (double*)std::malloc(m.vertices.size() * sizeof(double) + 8);
     *indices = (uint32_t*)std::malloc(m.indices.size() * sizeof(uint32_t) + 8);
@@ -705,11 +724,15 @@ size_t trgl_tga_max_size(int w, int h, int bpp) {
 
 int trgl_tga_encode(const uint8_t* pixels, int w, int h, int bpp, int vflip, int rle, uint8_t* out, size_t* out_len) {
     if (!pixels || !out || !out_len || w <= 0 || h <= 0 || w > 65535 || h > 65535 || !(bpp == 1 || bpp == 3 || bpp == 4)) return TRGL_E_INVALID;
-    TGAImage img(w, h, bpp);
-    std::memcpy(img.buffer(), pixels, size_t(w) * h * bpp);
-    std::vector<uint8_t> bytes = img.encode_tga(vflip != 0, rle != 0);
-    std::memcpy(out, bytes.data(), bytes.size());
-    *out_len = bytes.size();
+    try {
+        TGAImage img(w, h, bpp);
+        std::memcpy(img.buffer(), pixels, size_t(w) * h * bpp);
+        std::vector<uint8_t> bytes = img.encode_tga(vflip != 0, rle != 0);
+        std::memcpy(out, bytes.data(), bytes.size());
+        *out_len = bytes.size();
+    } catch (const std::bad_alloc&) {
+        return TRGL_E_NOMEM;
+    }
     return TRGL_OK;
 }
 
@@ -724,9 +747,13 @@ int trgl_tga_info(const uint8_t* file, size_t size, int* width, int* height, int
 
 int trgl_tga_decode(const uint8_t* file, size_t size, uint8_t* pixels) {
     if (!file || !pixels) return TRGL_E_INVALID;
-    TGAImage img;
-    if (!img.decode_tga(file, size)) return TRGL_E_INVALID;
-    std::memcpy(pixels, img.buffer(), size_t(img.width()) * img.height() * img.bytespp());
+    try {                                          // a header may claim 65535 x 65535 x 4 bytes: nothing throws across the C ABI
+        TGAImage img;
+        if (!img.decode_tga(file, size)) return TRGL_E_INVALID;
+        std::memcpy(pixels, img.buffer(), size_t(img.width()) * img.height() * img.bytespp());
+    } catch (const std::bad_alloc&) {
+        return TRGL_E_NOMEM;
+    }
     return TRGL_OK;
 }
 

@@ -67,6 +67,12 @@ struct DevStats {
 };
 #define TRGL_ZERO_KEY_EMPTY 0xffffffffffffffffull
 
+struct FrameParams;
+#ifdef __HIPCC__
+#define TRGL_HD __host__ __device__ __forceinline__
+#else
+#define TRGL_HD inline
+#endif
 struct FrameParams {
     uint8_t* fb;
     double*  zb;
@@ -75,8 +81,26 @@ struct FrameParams {
     int32_t  tiles_x, tiles_y;
     int32_t  strip_y0, strip_y1;      // rows this context owns
     int32_t  strip_ty0, strip_ty1;    // tile rows intersecting the strip: [ty0, ty1)
+    int32_t  il_tiles, il_world, il_rank;   // interleaved ownership (trgl_set_interleave): bands of il_tiles tile rows dealt round-robin to
+                                      // il_world contexts, this one takes band number == il_rank (mod il_world); il_tiles = 0: the strip above
     int32_t  init_from_clear;         // 1: tiles start from the clear values, not from HBM
     uint32_t clear_color;             // packed BGRA
     double   clear_z;
     double   vp[8];                   // rows 0 and 1 of the Viewport matrix (our_gl.cpp:117-121)
 };
+
+// ---- which tile rows a context owns (one strip, or interleaved bands) ----------------------------------------------
+TRGL_HD bool tile_row_owned(const FrameParams& fp, int ty) {
+    if (fp.il_tiles == 0) return ty >= fp.strip_ty0 && ty < fp.strip_ty1;
+    return (ty / fp.il_tiles) % fp.il_world == fp.il_rank;
+}
+// interleaved ownership: number of owned tile rows below row r
+TRGL_HD int il_owned_below(const FrameParams& fp, int r) {
+    const int period = fp.il_tiles * fp.il_world, q = r / period, m = r - q * period - fp.il_rank * fp.il_tiles;
+    return q * fp.il_tiles + (m < 0 ? 0 : (m > fp.il_tiles ? fp.il_tiles : m));
+}
+// ... and the j-th owned tile row counted from row ty0 (j = 0: the first owned row >= ty0)
+TRGL_HD int il_nth_owned_from(const FrameParams& fp, int ty0, int j) {
+    const int c = il_owned_below(fp, ty0) + j;
+    return (c / fp.il_tiles) * (fp.il_tiles * fp.il_world) + fp.il_rank * fp.il_tiles + (c % fp.il_tiles);
+}

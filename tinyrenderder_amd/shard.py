@@ -29,6 +29,37 @@ def gather_strips(full, width: int, height: int, bytes_per_pixel: int, rank: int
     return work if async_op else full
 
 
+def band_rows_of(height: int, world: int, rank: int, band_rows: int):
+    """Row ranges [y0, y1) of the bands rank `rank` owns under trgl_set_interleave(band_rows, rank, world)."""
+    period = band_rows * world
+    if height % period:
+        raise ValueError(f"height {height} is not a multiple of {world} ranks x {band_rows} rows per band")
+    return [(p * period + rank * band_rows, p * period + (rank + 1) * band_rows) for p in range(height // period)]
+
+
+class _Works:
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
+def gather_bands(full, width: int, height: int, bytes_per_pixel: int, band_rows: int, rank: int, world: int, group=None, async_op=False):
+    """Interleaved ownership: inside each period of world * band_rows rows the bands lie in rank order, so ONE in-place
+    all-gather per period (height / period of them, each over a contiguous byte range) joins the image."""
+    import torch.distributed as dist
+    row = width * bytes_per_pixel
+    period = band_rows * world
+    works = []
+    for (y0, y1) in band_rows_of(height, world, rank, band_rows):
+        p0 = (y0 // period) * period
+        out = full[p0 * row: (p0 + period) * row]
+        works.append(dist.all_gather_into_tensor(out, full[y0 * row: y1 * row], group=group, async_op=async_op))
+    return _Works(works) if async_op else full
+
+
 def reduce_stats(stats, device=None, group=None):
     """Combine per-rank trgl stats tuples (api.Stats.astuple()) into the whole-frame tuple.
     (The sign of a zero z-range end follows the first zero in submission order on ONE rank only; across ranks the

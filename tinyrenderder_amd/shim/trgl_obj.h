@@ -36,7 +36,7 @@ inline bool load(const std::string& path, Mesh& out) {
     std::string line;
     auto resolve = [](long idx, size_t count) -> int {           // OBJ indices are 1-based; negative = relative to the end
         if (idx > 0 && size_t(idx) <= count) return int(idx - 1);
-        if (idx < 0 && size_t(-idx) <= count) return int(long(count) + idx);
+        if (idx < 0 && size_t(-(idx + 1)) < count) return int(long(count) + idx);     // -(idx + 1): idx may be LONG_MIN (found by tests/host/fuzz_parsers)
         return -1;
     };
     while (std::getline(in, line)) {
