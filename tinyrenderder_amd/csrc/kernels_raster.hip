@@ -22,6 +22,20 @@ __device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b 
 // v_max_f64 as one instruction (a NaN operand yields the other one): for the depth maxima, where a pixel holding NaN can
 // never be written again (z < NaN is false), so leaving it out of a maximum keeps the maximum a valid bound
 __device__ __forceinline__ double vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// v_min3_f32 / v_max_f32 as single instructions (a NaN operand is skipped)
+__device__ __forceinline__ float fmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float fmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// double -> float rounded towards +inf / -inf (NaN stays NaN): bounds that stay bounds in single precision
+__device__ __forceinline__ float f32_up(double d) {
+    float f = (float)d;
+    if ((double)f < d) { const uint32_t b = __float_as_uint(f); f = __uint_as_float((b >> 31) ? b - 1u : b + 1u); }
+    return f;
+}
+__device__ __forceinline__ float f32_down(double d) {
+    float f = (float)d;
+    if ((double)f > d) { const uint32_t b = __float_as_uint(f); f = __uint_as_float((b >> 31) ? b + 1u : b - 1u); }
+    return f;
+}
 __device__ __forceinline__ int iclamp(int v, int lo, int hi) { return (v < lo) ? lo : (hi < v) ? hi : v; }
 __device__ __forceinline__ int x86_cvttsd2si(double d) {
     if (!(d > -2147483649.0 && d < 2147483648.0)) return INT_MIN;
@@ -631,6 +645,7 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
         // A triangle with no block left is skipped before its constants are broadcast.  On C4 this leaves 0.5x list
         // entries and 0.6x blocks of what a bbox scan with a per-triangle depth bound visits
         // (profiles/raster_counters.py; the diagnostic build checks that no dropped block would have written).
+        float bt;                                  // lane 16 r + 2 c: float upper bound of the stored maximum of the aligned 8x8 block (c, r)
         {
             const int cx = lane & 7, cy = lane >> 3;
             double m = -__builtin_inf();
@@ -640,6 +655,12 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
                 for (int dx = 0; dx < 4; ++dx) m = vmax(m, zt[lds_index(4 * cx + dx, 4 * cy + dy)]);
             }
             hz[lane] = m;
+            __builtin_amdgcn_wave_barrier();
+            const int f = (cy & 6) * 8 + (cx & 6);                                  // first cell of this lane's block
+            bt = f32_up(vmax(vmax(hz[f], hz[f + 1]), vmax(hz[f + 8], hz[f + 9])));
+            // bt is read with v_readlane from OTHER lanes inside the per-lane branch below: pin it here, in uniform control flow,
+            // or the compiler sinks part of its computation into the branch and the inactive lanes hold garbage
+            asm volatile("" : "+v"(bt));
             __builtin_amdgcn_wave_barrier();
         }
         unsigned long long todo;
@@ -655,7 +676,6 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
             if (!skip) {
                 rbox_l = (uint32_t)(x0 - px0) | ((uint32_t)(y0 - py0) << 8) | ((uint32_t)(x1 - x0) << 16) | ((uint32_t)(y1 - y0) << 24);
                 const int c0 = (x0 - px0) >> 3, c1 = (x1 - px0) >> 3, r0 = (y0 - py0) >> 3, r1 = (y1 - py0) >> 3;
-                const int cc0 = (x0 - px0) >> 2, cc1 = (x1 - px0) >> 2, cr0 = (y0 - py0) >> 2, cr1 = (y1 - py0) >> 2;   // in 4x4 cells
                 if (ruz_l == 0.0) {                // not well scaled: the literal path scans every block of the bbox
                     blocks_l = (((2u << c1) - (1u << c0)) & 0xfu) * 0x1111u & ((0xffffu >> (12 - 4 * r1)) & (0xffffu << (4 * r0)));
                 } else {
@@ -669,46 +689,62 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
                     const double s0x = __hiloint2double((int)cur.q[1].y, (int)cur.q[1].x), s0y = __hiloint2double((int)cur.q[1].w, (int)cur.q[1].z);
                     const double s1x = __hiloint2double((int)cur.q[2].y, (int)cur.q[2].x), s1y = __hiloint2double((int)cur.q[2].w, (int)cur.q[2].z);
                     const double uz_l = __hiloint2double((int)cur.q[3].y, (int)cur.q[3].x);
-                    // centre of the low corner pixel of block (c0, r0)
-                    const double X0 = (double)(px0 + 8 * c0) + 0.5, Y0 = (double)(py0 + 8 * r0) + 0.5;
-                    const double dx0 = ax - X0, dy0 = ay - Y0;
+                    // ---- the 16 block tests in SINGLE precision, straight-line ----
+                    // They only have to be conservative, not exact: every quantity is evaluated in float from the tile's block
+                    // (0,0) and stepped by FMAs, and the margins grow from 2^-40 to 2^-18 of the same magnitudes (S R for the edge
+                    // functions, zabs (R S / |u.z| + 1) for the depth plane), which covers the float roundings (a few 2^-24 of
+                    // those magnitudes: conversions of the inputs, products, sums, steps, a corner mis-chosen for a nearly flat
+                    // function) with a factor of >= 16 to spare and still is 1e-4 of a pixel.  Bounds that must not move the
+                    // wrong way are rounded outwards (u.z and zbound down, the stored maxima up); an absolute 2^-100 keeps the
+                    // margins above float denormal noise; overflow gives inf / NaN, which compare as "keep".
+                    // No loop whose trip count is the largest bbox of the batch, no LDS reads, half the issue cycles of fp64.
+                    const float X0 = (float)px0 + 0.5f, Y0 = (float)py0 + 0.5f;          // exact: px0 < 2^16
+                    const float dx0 = (float)(ax - (double)X0), dy0 = (float)(ay - (double)Y0);
+                    const float fs0x = (float)s0x, fs0y = (float)s0y, fs1x = (float)s1x, fs1y = (float)s1y, fruz = (float)ruz_l;
+                    const float fuz = f32_down(uz_l), fzb = f32_down(zbound);
                     // edge functions: u.x = s0y (ay-Y) - (ax-X) s1y, u.y = (ax-X) s1x - s0x (ay-Y), u.x + u.y
-                    const double gx = s1y - s1x, gy = s0x - s0y;                          // gradient of u.x + u.y
-                    const double oxa = s1y >= 0.0 ? 0.0 : 7.0, oya = s0y <= 0.0 ? 0.0 : 7.0;    // corner of min u.x
-                    const double oxb = s1x <= 0.0 ? 0.0 : 7.0, oyb = s0x >= 0.0 ? 0.0 : 7.0;    // corner of min u.y
-                    const double oxc = gx >= 0.0 ? 7.0 : 0.0, oyc = gy >= 0.0 ? 7.0 : 0.0;      // corner of max u.x+u.y
-                    double fa_row = s0y * (dy0 - oya) - (dx0 - oxa) * s1y;
-                    double fb_row = (dx0 - oxb) * s1x - s0x * (dy0 - oyb);
-                    double fc_row = (s0y * (dy0 - oyc) - (dx0 - oxc) * s1y) + ((dx0 - oxc) * s1x - s0x * (dy0 - oyc));
-                    const double R = fabs(dx0) + fabs(dy0) + 64.0;
-                    const double Sa = fabs(s0y) + fabs(s1y), Sb = fabs(s0x) + fabs(s1x);
-                    const double ma = 0x1p-40 * (Sa * R), mb = 0x1p-40 * (Sb * R);
-                    const double lim_c = uz_l - (ma + mb);
+                    const float gx = fs1y - fs1x, gy = fs0x - fs0y;                          // gradient of u.x + u.y
+                    const float oxa = fs1y >= 0.f ? 0.f : 7.f, oya = fs0y <= 0.f ? 0.f : 7.f;    // corner of min u.x
+                    const float oxb = fs1x <= 0.f ? 0.f : 7.f, oyb = fs0x >= 0.f ? 0.f : 7.f;    // corner of min u.y
+                    const float oxc = gx >= 0.f ? 7.f : 0.f, oyc = gy >= 0.f ? 7.f : 0.f;        // corner of max u.x+u.y
+                    const float fa0 = fs0y * (dy0 - oya) - (dx0 - oxa) * fs1y;
+                    const float fb0 = (dx0 - oxb) * fs1x - fs0x * (dy0 - oyb);
+                    const float fc0 = (fs0y * (dy0 - oyc) - (dx0 - oxc) * fs1y) + ((dx0 - oxc) * fs1x - fs0x * (dy0 - oyc));
+                    const float R = fabsf(dx0) + fabsf(dy0) + 64.0f;                      // >= |A - pixel| (L1) for every pixel of the tile
+                    const float Sa = fabsf(fs0y) + fabsf(fs1y), Sb = fabsf(fs0x) + fabsf(fs1x);
+                    const float ma = 0x1p-18f * (Sa * R) + 0x1p-100f, mb = 0x1p-18f * (Sb * R) + 0x1p-100f;
+                    const float lim_c = fuz - (ma + mb);
                     // depth plane: z0 + (u.y/u.z) dz1 + (u.x/u.z) dz2, minimum corner by the gradient's signs
-                    const double dz1 = z1 - z0, dz2 = z2 - z0;
-                    const double gzx = (s1y * dz2 - s1x * dz1) * ruz_l, gzy = (s0x * dz1 - s0y * dz2) * ruz_l;
-                    const double ux0 = s0y * dy0 - dx0 * s1y, uy0 = dx0 * s1x - s0x * dy0;
-                    const double mz = 0x1p-40 * (zabs * ((R * (Sa + Sb)) * fabs(ruz_l) + 1.0));
-                    double fz_row = ((z0 + (uy0 * ruz_l) * dz1) + (ux0 * ruz_l) * dz2) + ((gzx >= 0.0 ? 0.0 : 7.0) * gzx + (gzy >= 0.0 ? 0.0 : 7.0) * gzy) - mz;
-                    const double sax = 8.0 * s1y, say = -8.0 * s0y, sbx = -8.0 * s1x, sby = 8.0 * s0x, scx = 8.0 * gx, scy = 8.0 * gy;
-                    const double szx = 8.0 * gzx, szy = 8.0 * gzy;
+                    const float fz0v = (float)z0, dz1 = (float)(z1 - z0), dz2 = (float)(z2 - z0), fzabs = (float)zabs;
+                    const float gzx = (fs1y * dz2 - fs1x * dz1) * fruz, gzy = (fs0x * dz1 - fs0y * dz2) * fruz;
+                    const float ux0 = fs0y * dy0 - dx0 * fs1y, uy0 = dx0 * fs1x - fs0x * dy0;
+                    const float mz = 0x1p-18f * (fzabs * ((R * (Sa + Sb)) * fabsf(fruz) + 1.0f)) + 0x1p-100f;
+                    const float fz0 = ((fz0v + (uy0 * fruz) * dz1) + (ux0 * fruz) * dz2) + ((gzx >= 0.f ? 0.f : 7.f) * gzx + (gzy >= 0.f ? 0.f : 7.f) * gzy) - mz;
+                    const float sax = 8.f * fs1y, say = -8.f * fs0y, sbx = -8.f * fs1x, sby = 8.f * fs0x, scx = 8.f * gx, scy = 8.f * gy;
+                    const float szx = 8.f * gzx, szy = 8.f * gzy;
+                    // One number per block: keep <=> min(ma - fa, mb - fb, fc - lim_c, top - max(fz, fzb)) > 0.  (Dropping at
+                    // equality with a margin is still conservative.)  v_min / v_max skip a NaN operand, a NaN result reads as
+                    // "keep" through the integer compare, and triangles whose magnitudes could overflow float keep every block.
                     uint32_t mk = 0;
-                    for (int r = r0; r <= r1; ++r) {
-                        double fa = fa_row, fb = fb_row, fc = fc_row, fz = fz_row;
-                        // the cell rows of block row r that the clamped bbox reaches (the same row twice if only one)
-                        const int ra = 8 * max(2 * r, cr0), rb = 8 * min(2 * r + 1, cr1);
-                        for (int c = c0; c <= c1; ++c) {
-                            // stored maximum over the 4x4 cells of the block that hold pixels of the clamped bbox: no other
-                            // pixel of the block is scanned for this triangle
-                            const int ca = max(2 * c, cc0), cb = min(2 * c + 1, cc1);
-                            const double top = vmax(vmax(hz[ra + ca], hz[ra + cb]), vmax(hz[rb + ca], hz[rb + cb]));
-                            const bool outside = fa > ma || fb > mb || fc < lim_c;
-                            const bool behind = fz >= top || zbound >= top;
-                            if (!(outside || behind)) mk |= 1u << (4 * r + c);
-                            fa += sax; fb += sbx; fc += scx; fz += szx;
+                    const float dma = ma - fa0, dmb = mb - fb0, dmc = fc0 - lim_c;          // slacks at block (0,0); they step linearly
+                    float da_r = dma, db_r = dmb, dc_r = dmc, fz_r = fz0;
+#pragma nounroll
+                    for (int r = 0; r < 4; ++r) {                 // a real loop (wave-uniform trip count 4): keeps the register pressure of one row
+                        uint32_t row = 0;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float da = __builtin_fmaf(-(float)c, sax, da_r), db = __builtin_fmaf(-(float)c, sbx, db_r);
+                            const float dc = __builtin_fmaf((float)c, scx, dc_r), fz = __builtin_fmaf((float)c, szx, fz_r);
+                            const float top = __uint_as_float(bcast_u(__float_as_uint(bt), (uint32_t)(16 * r + 2 * c)));
+                            const float slack = fmin3(fmin3(da, db, dc), top - fmax2(fz, fzb), top - fmax2(fz, fzb));
+                            row |= ((int)__float_as_uint(slack) > 0) ? (1u << c) : 0u;
                         }
-                        fa_row += say; fb_row += sby; fc_row += scy; fz_row += szy;
+                        mk |= row << (4 * r);
+                        da_r -= say; db_r -= sby; dc_r += scy; fz_r += szy;
                     }
+                    if (!(R * (Sa + Sb) < 0x1p100f)) mk = 0xffffu;       // magnitudes float cannot hold (or NaN): no block test is trusted
+                    // only the blocks the clamped bbox reaches
+                    mk &= (((2u << c1) - (1u << c0)) & 0xfu) * 0x1111u & ((0xffffu >> (12 - 4 * r1)) & (0xffffu << (4 * r0)));
                     blocks_l = mk;
                 }
                 skip = blocks_l == 0;
