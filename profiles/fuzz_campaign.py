@@ -10,7 +10,9 @@ t0 = time.time(); bad = []
 for s in range(12, 12 + nf):
     try: T.test_fuzz_flat_scenes_against_oracle(s)
     except AssertionError as e: bad.append(("fuzz", s, str(e)[:80]))
+    if s % 100 == 0: print(f"fuzz seed {s}: {len(bad)} mismatching so far, {time.time() - t0:.0f} s", flush=True)
 for s in range(6, 6 + na):
     try: T.test_block_masks_on_adversarial_shapes(s)
     except AssertionError as e: bad.append(("adversarial", s, str(e)[:80]))
+    if s % 100 == 0: print(f"adversarial seed {s}: {len(bad)} mismatching so far, {time.time() - t0:.0f} s", flush=True)
 print(f"{nf} fuzz + {na} adversarial scenes in {time.time() - t0:.0f} s: {len(bad)} mismatching", bad[:5])

@@ -485,15 +485,27 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
     }
 }
 
+// per-tile slice [start, end) of the sorted pair list: four consecutive pairs per thread (one 16-byte load)
 __global__ __launch_bounds__(256) void k_bounds(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ pairs_total, uint32_t cap,
                                                 uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_end) {
     const unsigned long long P64 = *pairs_total;
     const uint32_t P = P64 > cap ? 0u : (uint32_t)P64;
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    uint32_t k = keys[p];
-    if (p == 0 || keys[p - 1] != k) tile_start[k] = p;
-    if (p == P - 1 || keys[p + 1] != k) tile_end[k] = p + 1;
+    const uint32_t p0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+    if (p0 >= P) return;
+    const uint4 q = *reinterpret_cast<const uint4*>(keys + p0);          // the buffers hold a multiple of 4 entries (grow_pairs)
+    const uint32_t k[4] = { q.x, q.y, q.z, q.w };
+    uint32_t prev = p0 ? keys[p0 - 1] : 0u;
+    const uint32_t after = (p0 + 4 < P) ? keys[p0 + 4] : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t p = p0 + (uint32_t)i;
+        if (p < P) {
+            const uint32_t next = i < 3 ? k[i + 1] : after;
+            if (p == 0 || prev != k[i]) tile_start[k[i]] = p;
+            if (p == P - 1 || next != k[i]) tile_end[k[i]] = p + 1;
+        }
+        prev = k[i];
+    }
 }
 
 }  // namespace
@@ -556,7 +568,7 @@ void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* v
 void launch_bounds(hipStream_t s, const uint32_t* keys, const unsigned long long* pairs_total, uint32_t cap,
                    uint32_t* tile_start, uint32_t* tile_end) {
     if (!cap) return;
-    hipLaunchKernelGGL(k_bounds, dim3((cap + 255) / 256), dim3(256), 0, s, keys, pairs_total, cap, tile_start, tile_end);
+    hipLaunchKernelGGL(k_bounds, dim3((cap + 1023) / 1024), dim3(256), 0, s, keys, pairs_total, cap, tile_start, tile_end);
 }
 
 }  // namespace trgl

@@ -276,7 +276,7 @@ struct TileState {
 #endif
     int lane, px0, py0, xa1, ya0, ya1;
     double lxm, lym;        // (lane&7) + 0.5 - 2^51 and (lane>>3) + 0.5 - 2^51: pixel centre = (2^51 + block origin) + this, exactly
-    int lrow, lsw;          // (lane>>3)*32 + (lane&7) and ((lane>>3)&3)<<3: the lane's part of lds_index() inside an aligned block
+    int lrow, lsw;          // lrow: the lane's part of lds_index() inside an aligned block, (lane>>3)*32 + (lane&7) + (((lane>>3)&3)<<3); lsw unused
     double* zt;
     uint8_t* fb_lane;       // address of this lane's pixel of block 0 in the framebuffer (colours are written straight to it)
     int bpp; uint32_t row_bytes;   // framebuffer bytes per pixel / per row
@@ -317,6 +317,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
             const int k = __builtin_ctz(m);
             m &= m - 1;
             const int cx = k & 3, cy = k >> 2;
+            const int k8 = (8 * cx) | (256 * cy);                             // wave-uniform
 #ifdef TRGL_DEBUG_COUNTERS
             const bool dropped = !((T.blocks >> k) & 1u);
             if (dropped) TRGL_DBG(6, 1);
@@ -332,7 +333,9 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
             // k_raster; -inf for a triangle that is not well scaled) and the z-test is a strict `<`, so a pixel with
             // zbound >= zold (or zold = NaN) cannot be written whatever its coverage: only lanes that can still win run the
             // coverage arithmetic, and a block without such a lane costs 8 vector instructions instead of 18.
-            const int li = (256 * cy + S.lrow) + ((8 * cx) ^ S.lsw);           // = lds_index(x, y) for an aligned block
+            // = lds_index(x, y) for an aligned block: (256 cy + lrow) + ((8 cx) ^ lsw), and since the three terms occupy
+            // disjoint bits (lrow: 0-2 and 5-7, lsw and 8 cx: 3-4, 256 cy: 8-9) it is ONE xor of a per-lane constant
+            const int li = S.lrow ^ k8;
             const double zold = S.zt[li];
             const bool alive = act && (T.zbound < zold);
 #ifdef TRGL_DEBUG_COUNTERS
@@ -410,7 +413,8 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
 #endif
                     S.zt[li] = z;                                             // :191
                     if (!shade_later) {                                       // :192, tgaimage.cpp:32-39: straight to the framebuffer
-                        uint8_t* dst = S.fb_lane + ((size_t)(8 * cy) * S.row_bytes + (size_t)(8 * cx) * S.bpp);
+                        // the block's offset from block 0 fits 32 bits (24 rows x < 2^18 bytes): scalar arithmetic, one 64-bit add per lane
+                        uint8_t* dst = S.fb_lane + (uint32_t)((uint32_t)(8 * cy) * S.row_bytes + (uint32_t)(8 * cx) * (uint32_t)S.bpp);
                         if (S.bpp == 3) { dst[0] = (uint8_t)color; dst[1] = (uint8_t)(color >> 8); dst[2] = (uint8_t)(color >> 16); }
                         else if (S.bpp == 4) *reinterpret_cast<uint32_t*>(dst) = color;
                         else for (int i = 0; i < S.bpp; ++i) dst[i] = (uint8_t)(color >> (8 * i));
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     S.row_px = (uint32_t)fp.W;
     S.id_lane = DEFERRED ? fp.idbuf + ((size_t)(py0 + (lane >> 3)) * fp.W + (size_t)(px0 + (lane & 7))) : nullptr;
     S.lxm = ((double)(lane & 7) + 0.5) - 0x1p51; S.lym = ((double)(lane >> 3) + 0.5) - 0x1p51;
-    S.lrow = (lane >> 3) * 32 + (lane & 7); S.lsw = ((lane >> 3) & 3) << 3;
+    S.lrow = ((lane >> 3) * 32 + (lane & 7)) | (((lane >> 3) & 3) << 3); S.lsw = 0;
     S.frags = 0; S.zmin = __builtin_inf(); S.zmax = -__builtin_inf();
     S.zero_locked = stats->zero_locked != 0;
 

@@ -55,6 +55,7 @@ struct trgl_ctx {
     struct { bool active = false; FrameParams fp; int flush_kind = 0; uint32_t cap = 0; int cur = 0; uint64_t N = 0; bool binned = false; } rp;
     hipEvent_t ev_pairs = nullptr;      // recorded behind the copy of the flush's pair count into pinned memory
     uint32_t* idbuf = nullptr; size_t cap_idbuf = 0;        // visibility buffer of PHONG / EYE flushes, [H][W]
+    uint8_t* pp_out = nullptr; size_t cap_pp = 0;           // trgl_postprocess: three [H][W][3] images + two 64-bit z-range keys, kept between calls
     uint32_t* blk_sums = nullptr; size_t cap_blk = 0;       // pairs per setup block of 256 triangles
     uint32_t* chunk_off = nullptr; size_t cap_chunk = 0;    // pairs before every 16th setup block
     size_t cap_tris = 0;
@@ -183,7 +184,7 @@ int trgl_destroy(trgl_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& s : c->stage) (void)hipFree(s.base);
     for (int i = 0; i < TRGL_MAX_TEXTURES; ++i) if (c->tex_host[i].data) (void)hipFree((void*)c->tex_host[i].data);
-    void* ptrs[] = { c->fb, c->zb, c->tex_dev, c->recs, c->cnt, c->idbuf, c->blk_sums, c->chunk_off, c->tilebox, c->keys[0], c->keys[1], c->vals[0],
+    void* ptrs[] = { c->fb, c->zb, c->tex_dev, c->recs, c->cnt, c->idbuf, c->pp_out, c->blk_sums, c->chunk_off, c->tilebox, c->keys[0], c->keys[1], c->vals[0],
                      c->vals[1], c->hist, c->scan_tmp, c->tile_start, c->draws_dev, c->stats_dev, c->items, c->n_items, c->item_stats };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->draws_pinned) (void)hipHostFree(c->draws_pinned);
@@ -382,9 +383,9 @@ int trgl_postprocess(trgl_ctx* c, const trgl_ssao_params* params, uint8_t* zimg,
         return fail(c, TRGL_E_INVALID, "trgl_postprocess: 1..16 directions, >= 1 step");
     int r = flush_sync(c); if (r) return r;
     const size_t npx = (size_t)c->W * c->H;
-    uint8_t* d_out = nullptr; unsigned long long* d_keys = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d_out, npx * 3 * 3));
-    HIPCHK(c, hipMalloc((void**)&d_keys, 16));
+    if ((r = grow(c, c->pp_out, c->cap_pp, npx * 9 + 64))) return r;      // allocated once per context, not per call
+    uint8_t* d_out = c->pp_out;
+    unsigned long long* d_keys = reinterpret_cast<unsigned long long*>(d_out + ((npx * 9 + 15) & ~size_t(15)));
     uint8_t* d_z = d_out; uint8_t* d_ao = d_out + npx * 3; uint8_t* d_fin = d_out + npx * 6;
     hipStream_t s = c->stream;
     if (zimg) launch_zimage(s, c->zb, c->W, c->H, d_keys, d_z);
@@ -398,7 +399,7 @@ int trgl_postprocess(trgl_ctx* c, const trgl_ssao_params* params, uint8_t* zimg,
                     sp.occlusion_threshold, sp.intensity, d_ao);
     }
     if (fin) {
-        if (c->bpp < 3) { (void)hipFree(d_out); (void)hipFree(d_keys); return fail(c, TRGL_E_UNSUPPORTED, "trgl_postprocess: composite needs an RGB(A) framebuffer"); }
+        if (c->bpp < 3) return fail(c, TRGL_E_UNSUPPORTED, "trgl_postprocess: composite needs an RGB(A) framebuffer");
         launch_composite(s, c->fb, c->bpp, d_ao, c->W, c->H, d_fin);
     }
     HIPCHK(c, hipGetLastError());
@@ -406,7 +407,6 @@ int trgl_postprocess(trgl_ctx* c, const trgl_ssao_params* params, uint8_t* zimg,
     if (ao) HIPCHK(c, hipMemcpyAsync(ao, d_ao, npx * 3, hipMemcpyDeviceToHost, s));
     if (fin) HIPCHK(c, hipMemcpyAsync(fin, d_fin, npx * 3, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, hipFree(d_out)); HIPCHK(c, hipFree(d_keys));
     return TRGL_OK;
 }
 
@@ -461,7 +461,7 @@ static int queue_binning(trgl_ctx* c, const FrameParams& fp, uint32_t cap, int* 
 
 static int grow_pairs(trgl_ctx* c, size_t need) {
     if (need <= c->cap_pairs) return TRGL_OK;
-    size_t ncap = need + need / 4 + 1024;
+    size_t ncap = (need + need / 4 + 1024 + 3) & ~size_t(3);     // a multiple of 4 entries: k_bounds reads 16 bytes at a time
     if (ncap > 0xfffffff0ull) ncap = 0xfffffff0ull;
     int r;
     for (int k = 0; k < 2; ++k) {

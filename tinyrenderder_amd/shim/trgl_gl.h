@@ -102,6 +102,14 @@ typedef vec<4> Triangle[3];
 
 namespace trgl_shim {
 
+// The image type is the caller's (the reference's TGAImage keeps its bytes-per-pixel private and buffer() non-const,
+// tgaimage.h:67-104): everything the shim needs goes through these three.
+template <class Img> inline int image_bpp(const Img& im) { return (im.width() > 0 && im.height() > 0) ? int(im.get(0, 0).bytespp) : 0; }   // TGAColor(p, bpp), tgaimage.h:46-50
+template <class Img> inline std::uint8_t* image_bytes(const Img& im) { return const_cast<Img&>(im).buffer(); }
+inline std::uint32_t pack_bgra(const TGAColor& c) {
+    return std::uint32_t(c.bgra[0]) | (std::uint32_t(c.bgra[1]) << 8) | (std::uint32_t(c.bgra[2]) << 16) | (std::uint32_t(c.bgra[3]) << 24);
+}
+
 struct State {
     trgl_ctx* ctx = nullptr;
     int w = 0, h = 0, bpp = 0;
@@ -127,10 +135,11 @@ inline int device_from_env() { const char* e = std::getenv("TRGL_DEVICE"); retur
 // make sure a context matching the framebuffer exists and holds the host's current pixels / depths
 inline void bind(TGAImage& fb) {
     State& s = state();
-    if (s.ctx && (s.w != fb.width() || s.h != fb.height() || s.bpp != fb.bytespp())) { trgl_destroy(s.ctx); s.ctx = nullptr; }
+    const int fb_bpp = image_bpp(fb);
+    if (s.ctx && (s.w != fb.width() || s.h != fb.height() || s.bpp != fb_bpp)) { trgl_destroy(s.ctx); s.ctx = nullptr; }
     if (!s.ctx) {
-        if (trgl_create(device_from_env(), fb.width(), fb.height(), fb.bytespp(), &s.ctx) != TRGL_OK) die("trgl_create", nullptr);
-        s.w = fb.width(); s.h = fb.height(); s.bpp = fb.bytespp();
+        if (trgl_create(device_from_env(), fb.width(), fb.height(), fb_bpp, &s.ctx) != TRGL_OK) die("trgl_create", nullptr);
+        s.w = fb.width(); s.h = fb.height(); s.bpp = fb_bpp;
         TRGL_SHIM_CHK(trgl_write_framebuffer(s.ctx, fb.buffer()));
         s.zbuffer_dirty_on_host = true;
     }
@@ -223,7 +232,7 @@ inline void gl_framebuffer_modified(TGAImage& fb) {
 inline void gl_upload_texture(TGAImage& framebuffer, int slot, const TGAImage& img) {
     trgl_shim::bind(framebuffer);
     trgl_shim::submit_batch();
-    TRGL_SHIM_CHK(trgl_upload_texture(trgl_shim::state().ctx, slot, img.buffer(), img.width(), img.height(), img.bytespp()));
+    TRGL_SHIM_CHK(trgl_upload_texture(trgl_shim::state().ctx, slot, trgl_shim::image_bytes(img), img.width(), img.height(), trgl_shim::image_bpp(img)));
 }
 
 // ---- our_gl.h:58 ---------------------------------------------------------------------------------
@@ -243,7 +252,7 @@ inline void rasterize(const Triangle& clip, const IShader& shader, TGAImage& fra
         submit_batch();
     if (!s.have_batch) { s.have_batch = true; s.kind = d.kind; s.uniforms = d.uniforms; s.viewport_at_batch = Viewport; }
     static_assert(sizeof(Triangle) == 12 * sizeof(double), "Triangle must be 12 packed doubles");
-    const double* cp = &clip[0][0];
+    const double* cp = reinterpret_cast<const double*>(&clip[0]);
     s.clip.insert(s.clip.end(), cp, cp + 12);                   // the Triangle memory image (our_gl.h:55)
     if (K) s.vary.insert(s.vary.end(), d.varyings, d.varyings + K);
     s.colors.push_back(d.color);
@@ -302,7 +311,7 @@ inline void gl_postprocess(TGAImage& framebuffer, TGAImage* zbuffer_image, TGAIm
     submit_batch();
     auto prep = [&](TGAImage* img) -> std::uint8_t* {
         if (!img) return nullptr;
-        if (img->width() != s.w || img->height() != s.h || img->bytespp() != 3) *img = TGAImage(s.w, s.h, TGAImage::RGB);
+        if (img->width() != s.w || img->height() != s.h || image_bpp(*img) != 3) *img = TGAImage(s.w, s.h, TGAImage::RGB);
         return img->buffer();
     };
     TRGL_SHIM_CHK(trgl_postprocess(s.ctx, nullptr, prep(zbuffer_image), prep(ao_map), prep(final_result)));

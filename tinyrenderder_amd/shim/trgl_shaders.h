@@ -8,7 +8,7 @@
 
 struct FlatShader : IShader {
     TGAColor color;
-    bool describe(trgl_shader_desc& d) const override { d.kind = TRGL_SHADER_FLAT; d.color = color.packed(); return true; }
+    bool describe(trgl_shader_desc& d) const override { d.kind = TRGL_SHADER_FLAT; d.color = trgl_shim::pack_bgra(color); return true; }
 };
 
 // classic tinyrenderer Gouraud: per-vertex intensity, colour = base * intensity (TGAColor::operator*, tgaimage.h:55-62)
@@ -16,7 +16,7 @@ struct GouraudShader : IShader {
     TGAColor base = TGAColor(255, 255, 255);
     double varying_intensity[3] = { 0, 0, 0 };
     bool describe(trgl_shader_desc& d) const override {
-        d.kind = TRGL_SHADER_GOURAUD; d.color = base.packed(); d.varyings = varying_intensity; return true;
+        d.kind = TRGL_SHADER_GOURAUD; d.color = trgl_shim::pack_bgra(base); d.varyings = varying_intensity; return true;
     }
 };
 
