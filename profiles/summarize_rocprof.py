@@ -78,7 +78,7 @@ if fetch and write:
     traffic = (2.0 * fetch + write) * 1024.0
     print(f"\n== k_raster HBM traffic per launch: FETCH_SIZE={fetch:.4g} KiB (x2 gfx950 wide-read correction), "
           f"WRITE_SIZE={write:.4g} KiB -> {traffic/1e6:.1f} MB ==")
-    json.dump({"workload": "c4_4096x4096_10000000", "raster_hbm_bytes_per_launch": traffic,
+    json.dump({"workload": "c4_4096x4096_10000000", "round": os.path.basename(os.path.normpath(out)).replace("prof_", ""), "raster_hbm_bytes_per_launch": traffic,
                "fetch_size_kib": fetch, "write_size_kib": write,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024"},
               open(os.path.join(out, "traffic.json"), "w"), indent=1)

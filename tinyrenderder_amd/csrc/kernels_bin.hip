@@ -293,29 +293,40 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const uint32_t* __r
 // ---------------------------------------------------------------------------------------------
 constexpr int EXPAND_CHUNK = 16;
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_chunk_spine(const uint32_t* __restrict__ blk_sums, uint32_t nblk,
+constexpr int SPINE_THREADS = 1024;
+__global__ __launch_bounds__(SPINE_THREADS) void k_chunk_spine(const uint32_t* __restrict__ blk_sums, uint32_t nblk,
                                                                uint32_t* __restrict__ chunk_off,
                                                                unsigned long long* __restrict__ total64) {
-    __shared__ uint32_t smem[4];
-    __shared__ unsigned long long smem64[4];
+    __shared__ unsigned long long s_wave[SPINE_THREADS / 64];
     const uint32_t nchunks = (nblk + EXPAND_CHUNK - 1) / EXPAND_CHUNK;
-    // The offsets are 32-bit by design (a flush holds fewer than 2^32 pairs); the TOTAL is accumulated in 64 bits so that a
-    // flush beyond that limit is seen as such by the host (and by the guards of the kernels queued behind this one)
-    // instead of wrapping: 100 k full-screen triangles at 8192^2 are 6.5e9 pairs.
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // One chunk (16 block sums = 64 bytes) per thread, 1024 chunks per round.  Offsets are 32-bit by design (a flush holds
+    // fewer than 2^32 pairs); everything is accumulated in 64 bits so that a flush beyond that limit is seen as such by the
+    // host and by the guards of the kernels queued behind this one instead of wrapping (100 k full-screen triangles at
+    // 8192^2 are 6.5e9 pairs).
     unsigned long long running = 0;
-    for (uint32_t start = 0; start < nchunks; start += SCAN_THREADS) {
+    for (uint32_t start = 0; start < nchunks; start += SPINE_THREADS) {
         const uint32_t c = start + threadIdx.x;
-        unsigned long long v64 = 0;
-        if (c < nchunks)
-            for (uint32_t q = c * EXPAND_CHUNK; q < min(nblk, (c + 1) * EXPAND_CHUNK); ++q) v64 += blk_sums[q];
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan((uint32_t)v64, smem, &tot);
-        if (c < nchunks) chunk_off[c] = (uint32_t)running + ex;
-        unsigned long long w64 = v64;
-        for (int o = 32; o; o >>= 1) w64 += __shfl_xor(w64, o);
-        if ((threadIdx.x & 63) == 0) smem64[threadIdx.x >> 6] = w64;
+        unsigned long long v = 0;
+        if (c < nchunks) {
+            const uint32_t q0 = c * EXPAND_CHUNK;
+            if (q0 + EXPAND_CHUNK <= nblk) {
+                const uint4* p4 = reinterpret_cast<const uint4*>(blk_sums + q0);
+#pragma unroll
+                for (int k = 0; k < EXPAND_CHUNK / 4; ++k) { const uint4 t = p4[k]; v += (unsigned long long)t.x + t.y + t.z + t.w; }
+            } else {
+                for (uint32_t q = q0; q < nblk; ++q) v += blk_sums[q];
+            }
+        }
+        unsigned long long inc = v;                                   // inclusive scan inside the wave
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) s_wave[w] = inc;
         __syncthreads();
-        running += smem64[0] + smem64[1] + smem64[2] + smem64[3];
+        unsigned long long base = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < SPINE_THREADS / 64; ++k) { const unsigned long long t = s_wave[k]; if (k < w) base += t; tot += t; }
+        if (c < nchunks) chunk_off[c] = (uint32_t)(running + base + inc - v);
+        running += tot;
         __syncthreads();
     }
     if (threadIdx.x == 0) *total64 = running;
@@ -523,7 +534,7 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc* draws_de
 }
 
 void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, uint32_t* chunk_off, unsigned long long* total64) {
-    hipLaunchKernelGGL(k_chunk_spine, dim3(1), dim3(SCAN_THREADS), 0, s, blk_sums, nblk, chunk_off, total64);
+    hipLaunchKernelGGL(k_chunk_spine, dim3(1), dim3(SPINE_THREADS), 0, s, blk_sums, nblk, chunk_off, total64);
 }
 
 uint32_t scan_num_blocks(uint64_t n) { return (uint32_t)((n + SCAN_ELEMS - 1) / SCAN_ELEMS); }
