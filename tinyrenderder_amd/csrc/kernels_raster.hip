@@ -417,7 +417,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                         uint8_t* dst = S.fb_lane + (uint32_t)((uint32_t)(8 * cy) * S.row_bytes + (uint32_t)(8 * cx) * (uint32_t)S.bpp);
                         if (S.bpp == 3) { dst[0] = (uint8_t)color; dst[1] = (uint8_t)(color >> 8); dst[2] = (uint8_t)(color >> 16); }
                         else if (S.bpp == 4) *reinterpret_cast<uint32_t*>(dst) = color;
-                        else for (int i = 0; i < S.bpp; ++i) dst[i] = (uint8_t)(color >> (8 * i));
+                        else dst[0] = (uint8_t)color;                          // bpp is 1, 3 or 4 (trgl_create)
                     }
                     ++S.frags;                                                // :194
                     // :197-198.  After a few fragments a lane's running min/max rarely moves, so the updates
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         uint8_t* dst = fp.fb + idx * fp.bpp;                                               // TGAImage::set, tgaimage.cpp:32-39
         if (fp.bpp == 3) { dst[0] = (uint8_t)color; dst[1] = (uint8_t)(color >> 8); dst[2] = (uint8_t)(color >> 16); }
         else if (fp.bpp == 4) *reinterpret_cast<uint32_t*>(dst) = color;
-        else for (int i = 0; i < fp.bpp; ++i) dst[i] = (uint8_t)(color >> (8 * i));
+        else dst[0] = (uint8_t)color;                                  // bpp is 1, 3 or 4 (trgl_create)
     }
 }
 
