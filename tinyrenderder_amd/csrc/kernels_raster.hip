@@ -293,7 +293,7 @@ struct TileState {
 constexpr int KIND_ANY = 4;
 struct VaryQ { uint4 v[2]; uint32_t color; };       // GOURAUD: three intensities + the base colour of lane j's triangle
 
-template <int KIND, bool WELL_SCALED>
+template <int KIND, bool WELL_SCALED, int BPP>
 __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& V, TileState& S,
                                                 const DrawDesc* __restrict__ draws,
                                                 const DevTexture* __restrict__ tex, DevStats* __restrict__ stats) {
@@ -415,9 +415,10 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                     if (!shade_later) {                                       // :192, tgaimage.cpp:32-39: straight to the framebuffer
                         // the block's offset from block 0 fits 32 bits (24 rows x < 2^18 bytes): scalar arithmetic, one 64-bit add per lane
                         uint8_t* dst = S.fb_lane + (uint32_t)((uint32_t)(8 * cy) * S.row_bytes + (uint32_t)(8 * cx) * (uint32_t)S.bpp);
-                        if (S.bpp == 3) { dst[0] = (uint8_t)color; dst[1] = (uint8_t)(color >> 8); dst[2] = (uint8_t)(color >> 16); }
-                        else if (S.bpp == 4) *reinterpret_cast<uint32_t*>(dst) = color;
-                        else dst[0] = (uint8_t)color;                          // bpp is 1, 3 or 4 (trgl_create)
+                        const int bpp = BPP ? BPP : S.bpp;                     // 1, 3 or 4 (trgl_create); compile-time in the FLAT kernels
+                        if (bpp == 3) { *reinterpret_cast<uint16_t*>(dst) = (uint16_t)color; dst[2] = (uint8_t)(color >> 16); }   // TGAImage::set: b, g, r
+                        else if (bpp == 4) *reinterpret_cast<uint32_t*>(dst) = color;
+                        else dst[0] = (uint8_t)color;
                     }
                     ++S.frags;                                                // :194
                     // :197-198.  After a few fragments a lane's running min/max rarely moves, so the updates
@@ -497,7 +498,8 @@ __device__ __forceinline__ void tile_clear_color(const FrameParams& fp, int lane
 
 }
 
-template <int KIND>
+// BPP: the framebuffer's bytes per pixel when the kernel is compiled for one (3 or 4, FLAT only), 0 = read from FrameParams
+template <int KIND, int BPP = 0>
 __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu((KIND == TRGL_SHADER_GOURAUD || KIND == 4) ? 3 : 4, 4))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
                                                 const uint32_t* __restrict__ tile_start,
@@ -811,8 +813,8 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
                 }
                 TRGL_DBG(0, 1);                                                    // list entries rasterized (not skipped)
                 // "well scaled" is a property of the triangle (k_setup leaves ruz = 0 otherwise): wave-uniform by construction
-                if (bw & 0x10000u) raster_triangle<KIND, true>(T, V, S, draws, tex, stats);
-                else raster_triangle<KIND, false>(T, V, S, draws, tex, stats);
+                if (bw & 0x10000u) raster_triangle<KIND, true, BPP>(T, V, S, draws, tex, stats);
+                else raster_triangle<KIND, false, BPP>(T, V, S, draws, tex, stats);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -1088,9 +1090,13 @@ void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER
     hipLaunchKernelGGL(k_make_items, dim3((tiles + 255) / 256), dim3(256), 0, s, fp, tile_start, tile_end, split_len, items, n_items);
     dim3 grid((max_items + TRGL_WAVES_PER_BLOCK - 1) / TRGL_WAVES_PER_BLOCK);
     if (ev_before) (void)hipEventRecord(ev_before, s);
-#define TRGL_LAUNCH_RASTER(K) hipLaunchKernelGGL(k_raster<K>, grid, dim3(64 * TRGL_WAVES_PER_BLOCK), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items, item_stats)
+#define TRGL_LAUNCH_RASTER(...) hipLaunchKernelGGL((k_raster<__VA_ARGS__>), grid, dim3(64 * TRGL_WAVES_PER_BLOCK), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items, item_stats)
     switch (kind) {
-    case TRGL_SHADER_FLAT:    TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT); break;
+    case TRGL_SHADER_FLAT:
+        if (fp.bpp == 3) TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT, 3);
+        else if (fp.bpp == 4) TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT, 4);
+        else TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT);
+        break;
     case TRGL_SHADER_GOURAUD: TRGL_LAUNCH_RASTER(TRGL_SHADER_GOURAUD); break;
     case TRGL_SHADER_PHONG:   TRGL_LAUNCH_RASTER(TRGL_SHADER_PHONG); break;
     case TRGL_SHADER_EYE:     TRGL_LAUNCH_RASTER(TRGL_SHADER_EYE); break;
