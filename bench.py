@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--partition", default="strips", choices=["strips", "bands"],
                     help="N > 1: one horizontal strip per rank (default), or bands of --band-rows rows dealt round-robin (load-balanced)")
     ap.add_argument("--band-rows", type=int, default=128)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI, the measured configuration) or gloo: a rehearsal of the N > 1 code path with all ranks "
+                         "on ONE GPU (a 1-GPU box cannot host two RCCL ranks); its numbers mean nothing")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL strip-gather path even with one rank (rehearsal)")
     ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3"],
                     help="c4 (default, the metric's config): 10 M random flat triangles; c2/c3: PHONG head stand-in at 2048/4096")
@@ -141,14 +144,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    dev = local_rank % max(torch.cuda.device_count(), 1) if args.backend == "gloo" else local_rank
+    torch.cuda.set_device(dev)
     dist = None
     use_dist = world > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from tinyrenderder_amd.api import PHONG, make_uniforms
     W = H = args.size
@@ -170,7 +177,7 @@ def main():
         wl_name = f"configs[{1 if args.workload == 'c2' else 2}]: {N}-triangle head stand-in, {W}x{H}, PHONG, maps {sorted(textures)}"
     dclip = torch.from_numpy(clip).cuda()
 
-    ctx = Context(W, H, 3, device=local_rank)
+    ctx = Context(W, H, 3, device=dev)
     for slot, t in textures.items():
         ctx.upload_texture(slot, t)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)          # order with torch / RCCL on one stream

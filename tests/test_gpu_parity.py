@@ -642,3 +642,24 @@ def test_interleaved_bands_compose(name, world, band):
         assert rst[0] == st[0] and rst[2:6] == st[2:6]
         frags += rst[1]; zmin = min(zmin, rst[6]); zmax = max(zmax, rst[7])
     assert (frags, zmin, zmax) == (st[1], st[6], st[7])
+
+
+@pytest.mark.parametrize("partition", ["strips", "bands"])
+def test_bench_two_ranks_on_one_gpu_over_gloo(partition):
+    """bench.py's N = 2 code path run for real as two processes (torch.distributed.run), both on this box's one GPU, with gloo
+    as the transport because RCCL refuses two ranks on one device: strip / band contexts, shard.StripLoop with the asynchronous
+    in-place gather into an alias of each context's framebuffer, the barrier + max-over-ranks timing, and the parity gate on
+    rank 0's GATHERED framebuffer against the reference's full-size digest (4096^2, 10 M triangles).  The throughput it prints is
+    meaningless (two processes share a GPU and the strips travel through host memory)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    port = 29600 + (os.getpid() % 300) + (7 if partition == "bands" else 0)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--partition", partition,
+                        "--steps", "3", "--warmup", "1", "--cpu-sample", "0"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["parity"]["checked"] and d["parity"]["ok"], d["parity"]
