@@ -276,7 +276,7 @@ struct TileState {
 #endif
     int lane, px0, py0, xa1, ya0, ya1;
     double lxm, lym;        // (lane&7) + 0.5 - 2^51 and (lane>>3) + 0.5 - 2^51: pixel centre = (2^51 + block origin) + this, exactly
-    int lrow, lsw;          // lrow: the lane's part of lds_index() inside an aligned block, (lane>>3)*32 + (lane&7) + (((lane>>3)&3)<<3); lsw unused
+    int lrow;               // the lane's part of lds_index() inside an aligned block: (lane>>3)*32 + (lane&7) + (((lane>>3)&3)<<3)
     double* zt;
     uint8_t* fb_lane;       // address of this lane's pixel of block 0 in the framebuffer (colours are written straight to it)
     int bpp; uint32_t row_bytes;   // framebuffer bytes per pixel / per row
@@ -333,8 +333,8 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
             // k_raster; -inf for a triangle that is not well scaled) and the z-test is a strict `<`, so a pixel with
             // zbound >= zold (or zold = NaN) cannot be written whatever its coverage: only lanes that can still win run the
             // coverage arithmetic, and a block without such a lane costs 8 vector instructions instead of 18.
-            // = lds_index(x, y) for an aligned block: (256 cy + lrow) + ((8 cx) ^ lsw), and since the three terms occupy
-            // disjoint bits (lrow: 0-2 and 5-7, lsw and 8 cx: 3-4, 256 cy: 8-9) it is ONE xor of a per-lane constant
+            // = lds_index(x, y) for an aligned block: row and column of the lane occupy bits 5-7 and 0-2, the row swizzle and 8 cx
+            // bits 3-4, 256 cy bits 8-9: the whole index is ONE xor of a per-lane constant with a scalar
             const int li = S.lrow ^ k8;
             const double zold = S.zt[li];
             const bool alive = act && (T.zbound < zold);
@@ -584,12 +584,8 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     if (fp.init_from_clear || DEFERRED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     constexpr bool FLAT_ONLY = KIND == TRGL_SHADER_FLAT;
-    // GOURAUD's 3 intensities + base colour ride along with the records (lane j of V); PHONG / EYE have 24 doubles of
-    // varyings: holding them per lane costs 48 VGPRs and a third wave per SIMD, which is worth more than the latency
-    // of fetching them where a block shades (measured: 232 -> <=168 VGPRs).  For the same reason only the cheap kinds
-    // keep the next batch of records in flight.
+    // GOURAUD's 3 intensities + base colour ride along with the records (lane j of V); PHONG / EYE are shaded by k_shade.
     constexpr bool HAS_V = KIND == TRGL_SHADER_GOURAUD;
-    constexpr bool PREFETCH = false;
     TileState S;
 #ifdef TRGL_DEBUG_COUNTERS
     for (int k = 0; k < 8; ++k) S.dbg[k] = 0;
@@ -600,15 +596,13 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     S.row_px = (uint32_t)fp.W;
     S.id_lane = DEFERRED ? fp.idbuf + ((size_t)(py0 + (lane >> 3)) * fp.W + (size_t)(px0 + (lane & 7))) : nullptr;
     S.lxm = ((double)(lane & 7) + 0.5) - 0x1p51; S.lym = ((double)(lane >> 3) + 0.5) - 0x1p51;
-    S.lrow = ((lane >> 3) * 32 + (lane & 7)) | (((lane >> 3) & 3) << 3); S.lsw = 0;
+    S.lrow = ((lane >> 3) * 32 + (lane & 7)) | (((lane >> 3) & 3) << 3);
     S.frags = 0; S.zmin = __builtin_inf(); S.zmax = -__builtin_inf();
     S.zero_locked = stats->zero_locked != 0;
 
     // ---- the tile's triangles, in submission order --------------------------------------------
-    // 64 records at a time: lane i holds the 128-B record of the batch's i-th triangle in registers
-    // (the next batch is already in flight while this one is rasterized), and the per-triangle
-    // constants are broadcast with v_readlane into SGPRs.  One HBM round trip per 64 triangles
-    // instead of two dependent ones per triangle.
+    // 64 records at a time: lane i holds the 128-B record of the batch's i-th triangle in registers for the batch phase
+    // (block masks, one triangle per lane); the survivors' constants then go through LDS slots to all lanes.
     RecQ cur;
     if (beg < end) {                     // an empty tile must not touch vals/recs at all
         uint32_t p = beg + lane;
@@ -624,11 +618,6 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     V.color = 0; V.v[0] = make_uint4(0, 0, 0, 0); V.v[1] = make_uint4(0, 0, 0, 0);
     for (uint32_t bs = beg; bs < end; bs += 64) {
         const uint32_t nbatch = min(64u, end - bs);
-        RecQ nxt = cur;
-        if (PREFETCH && bs + 64 < end) {
-            uint32_t p = bs + 64 + lane;
-            nxt = load_rec(recs, vals[p < end ? p : end - 1], true);
-        }
         // ---- block masks, once per batch of 64 list entries ----------------------------------------------------
         // Lane l owns the 4x4-pixel cell (l&7, l>>3) of the tile and reduces the depths currently stored in it (rows
         // and columns this item does not own count as -inf: they are never scanned); 16 lanes then publish the
@@ -818,8 +807,7 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (PREFETCH) cur = nxt;
-        else if (bs + 64 < end) {
+        if (bs + 64 < end) {              // (holding the next batch's records during the scan costs a wave per SIMD; measured, not kept)
             uint32_t p = bs + 64 + lane;
             cur = load_rec(recs, vals[p < end ? p : end - 1], true);
         }
