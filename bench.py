@@ -108,6 +108,37 @@ def end_to_end(ctx, kind, clip, vary, col, uniforms, frames=2):
             "includes": "H2D of the clip-space stream (+ varyings/colours) from pageable host memory, flush, D2H of the framebuffer"}
 
 
+def frames_in_flight(Context, W, H, kind, dclip, dcol, fb_expected, frames=20, depth=2):
+    """Throughput with `depth` frames in flight: `depth` contexts, each on its own HIP stream, render the same frame in
+    turn, so that the HBM-bound phases of one frame (k_setup, binning) may run beside the issue-bound k_raster of the
+    previous one.  Same work per frame as a timed step (clear, draw, flush); every context's last frame is compared with
+    the timed frame.  Reported next to `value`, never as `value`: a step of the contract is one frame start to finish."""
+    import torch
+    ctxs = [Context(W, H, 3) for _ in range(depth)]
+
+    def begin(c):
+        c.clear(); c.draw(kind, dclip, colors=dcol, device=True); c.flush_begin()
+    for c in ctxs:
+        begin(c); c.flush_end(); c.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pending = []
+    for f in range(frames):
+        if len(pending) == depth:
+            pending.pop(0).flush_end()
+        begin(ctxs[f % depth]); pending.append(ctxs[f % depth])
+    for c in pending:
+        c.flush_end()
+    for c in ctxs:
+        c.sync()
+    dt = time.perf_counter() - t0
+    same = all(np.array_equal(c.read_framebuffer(), fb_expected) for c in ctxs) if fb_expected is not None else None
+    for c in ctxs:
+        c.close()
+    return {"depth": depth, "frames": frames, "ms_per_frame": dt * 1e3 / frames, "triangles_per_s": dclip.shape[0] * frames / dt,
+            "frames_equal_timed_frame": same}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +152,8 @@ def main():
                          "that the k_raster statistics hold the full launches only)")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (profiling runs)")
     ap.add_argument("--end-to-end-frames", type=int, default=2, help="PCIe-inclusive frames timed after the run (0 = skip)")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="after the run: throughput with this many frames in flight on separate streams (reported beside value; 1 = skip)")
     ap.add_argument("--partition", default="strips", choices=["strips", "bands"],
                     help="N > 1: one horizontal strip per rank (default), or bands of --band-rows rows dealt round-robin (load-balanced)")
     ap.add_argument("--band-rows", type=int, default=128)
@@ -250,7 +283,7 @@ def main():
     ctx.set_profiling(False)
 
     # ---- parity gate: no timing is reported unless the frame that was timed is the reference's ----
-    parity, cpu, e2e = {"checked": False, "ok": None}, None, None
+    parity, cpu, e2e, inflight = {"checked": False, "ok": None}, None, None, None
     golden_name = "c4_4096_10m" if (args.workload == "c4" and W == 4096 and N == 10_000_000) else None
     if rank == 0 and world == 1 and not args.no_parity:
         cpu_frame, checker, n_par = None, None, N
@@ -273,6 +306,8 @@ def main():
                 parity["ok"] = bool(parity["ok"] and parity["timed_frame_equals_parity_frame"])
         if args.end_to_end_frames > 0:
             e2e = end_to_end(ctx, kind, clip, None if dvary is None else hd["varyings"], col, uniforms, args.end_to_end_frames)
+        if args.frames_in_flight > 1 and kind == FLAT:
+            inflight = frames_in_flight(Context, W, H, kind, dclip, dcol, fb_timed, frames=args.steps, depth=args.frames_in_flight)
     elif rank == 0 and world > 1 and golden_name and not args.no_parity:
         # multi-rank: rank 0 holds the gathered framebuffer (colour strips only travel); compare it with the reference's digest
         import hashlib
@@ -340,6 +375,8 @@ def main():
             out["write_path"] = write_path
         if e2e:
             out["end_to_end"] = e2e
+        if inflight:
+            out["frames_in_flight"] = inflight
         if cpu:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
