@@ -10,8 +10,10 @@ h = C.c_void_p(); assert L.trgl_create(0, W, H, 3, C.byref(h)) == 0
 dclip = torch.from_numpy(clip).cuda(); dcol = torch.from_numpy(col.view(np.int32)).cuda()
 L.trgl_draw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
 assert L.trgl_draw(h, 0, None, dclip.data_ptr(), None, dcol.data_ptr(), N, 1) == 0
-out = (C.c_ulonglong * 8)(); L.trgl_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+out = (C.c_ulonglong * 16)(); L.trgl_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
 assert L.trgl_debug_counters(h, out) == 0
-names = ["triangles scanned (slots read)", "blocks visited", "blocks reaching the divisions", "lanes that could still win (z-alive)", "list entries (pairs)",
-         "visited blocks with no z-alive lane", "blocks dropped by the per-lane masks", "... of which wrote a pixel (must be 0)"]
+names = ["triangles scanned (slots read)", "blocks visited", "blocks reaching the divisions", "lanes of visited blocks inside the bbox", "list entries (pairs)",
+         "visited blocks that skip the divisions", "blocks dropped by the per-lane masks", "... of which wrote a pixel (must be 0)",
+         "lanes that ran the divisions", "... and wrote their pixel", "blocks that ran the divisions and wrote nothing",
+         "blocks the depth-plane test spares the divisions", "lanes it would wrongly kill (must be 0)"]
 for n, v in zip(names, out): print(f"{n:44s} {v:>12d}  per triangle {v / N:.3f}")

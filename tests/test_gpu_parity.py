@@ -180,6 +180,54 @@ def test_block_masks_on_adversarial_shapes(seed):
     assert st == o.stats
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_depth_plane_early_test_on_extreme_depths(seed):
+    """k_raster skips the three divisions of a block when a plane c0 + u.y g1 + u.x g2 (a lower bound of every covered pixel's
+    computed z, 2^-40 max|z_i| below the exact plane) is not below the stored depth.  Depths chosen against it, on dense
+    overdraw: vertices at +-1e0..1e300 next to one inside [-1,1] (slopes overflow: the test must switch itself off), depths of
+    1e-300..1e-320 (subnormal planes), planes one ulp from flat, exactly flat duplicates (ties), perspective w, and a stored
+    z-buffer with NaN, -inf, +inf and finite patches.  A pixel killed wrongly is a missing fragment: bits must equal the oracle's."""
+    rng = scenes.SplitMix64(8000 + seed)
+    W, H = 192, 128
+    n = 15000
+    clip, col = scenes.random_triangles(n, W, H, seed=8100 + seed, rmin=2, rmax=30, perspective_w=bool(seed & 1))
+    clip = clip.copy()
+    u = rng.uniform(n * 4).reshape(n, 4)
+    for i in range(n):
+        kind = i % 8
+        w = clip[i, [3, 7, 11]]
+        z = clip[i, [2, 6, 10]] / w                        # NDC depths of the generator, inside [-1, 1]
+        if kind == 0:                                      # two huge vertices, every sign
+            e1, e2 = 300.0 * u[i, 0], 300.0 * u[i, 1]
+            z = np.array([z[0], (1 if u[i, 2] < 0.5 else -1) * 10.0 ** e1, (1 if u[i, 3] < 0.5 else -1) * 10.0 ** e2])
+        elif kind == 1:                                    # tiny, down to subnormals
+            z = z * 10.0 ** (-300.0 - 20.0 * u[i, 0])
+        elif kind == 2:                                    # one ulp from flat
+            z = np.array([z[0], np.nextafter(z[0], 2.0), z[0] if u[i, 0] < 0.5 else np.nextafter(z[0], -2.0)])
+        elif kind == 3:                                    # exactly flat, few distinct values: ties between triangles
+            z = np.full(3, np.round(z[0] * 8) / 8)
+        elif kind == 4:                                    # one vertex beyond the far plane, one beyond the near plane
+            z = np.array([z[0], 1.0 + 50.0 * u[i, 0], -1.0 - 50.0 * u[i, 1]])
+        clip[i, [2, 6, 10]] = z * w
+    # stored depths the flush starts from: finite band, NaN, -inf, +inf columns
+    z0 = np.full((H, W), np.inf)
+    z0[:, 0:40] = 0.25; z0[:, 40:70] = np.nan; z0[:, 70:100] = -np.inf; z0[:, 100:130] = -0.5; z0[10:20, :] = 1e-310
+    with Context(W, H, 3) as ctx:
+        ctx.clear((1, 2, 3, 255))
+        ctx.write_zbuffer(z0)
+        half = n // 2
+        ctx.draw(FLAT, clip[:half], colors=col[:half]); ctx.flush()
+        ctx.draw(FLAT, clip[half:], colors=col[half:])
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    o = orc.Oracle(W, H, 3, clear_bgra=(1, 2, 3, 255))
+    o.z[:] = z0
+    o.draw(orc.FLAT, clip, colors=col)
+    assert np.array_equal(z.view(np.uint64), o.z.view(np.uint64))
+    assert np.array_equal(fb, o.fb)
+    assert st == o.stats
+    assert st[1] > 50_000
+
+
 @pytest.mark.parametrize("bpp", [1, 4])
 def test_phong_and_eye_on_gray_and_rgba_framebuffers(bpp):
     """TGAImage::set copies bytespp bytes of the returned colour (tgaimage.cpp:32-39): k_shade must do the same on a

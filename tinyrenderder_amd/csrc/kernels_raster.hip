@@ -251,28 +251,29 @@ __device__ __forceinline__ double div_by_uz(double a, double uz, double ruz) {
 // Only the three words that steer control flow are made wave-uniform (v_readfirstlane).
 struct TriConst {
     double ax, ay, s0x, s0y, s1x, s1y, uz, ruz, z0, z1, z2, iw0, iw1, iw2;
-    double zbound;      // lower bound of the depth of any covered pixel (-inf if the triangle is not well scaled)
+    double c0, g1, g2;  // depth plane for the per-pixel early test: every covered pixel has z > c0 + u.y g1 + u.x g2 (c0 = -inf: no test)
     uint32_t color, dl, tri;    // per-lane copies
     uint32_t rbox;      // SGPR: rx0 | ry0<<8 | (rx1-rx0)<<16 | (ry1-ry0)<<24, the clamped bbox relative to the tile origin
     uint32_t blocks;    // SGPR: bit k set: the aligned 8x8 block k of the tile may hold covered pixels that pass the z-test
     uint32_t j;         // SGPR: lane of the batch that holds this triangle's record (GOURAUD varyings ride in that lane)
 };
 // LDS slot of one surviving triangle of a batch: 16-byte chunks
-//   0: ax ay   1: s0x s0y   2: s1x s1y   3: uz ruz   4: z0 z1   5: z2 zbound   6: rbox, blocks | lane << 24, color, tri
-//   (kinds other than FLAT)  7: iw0 iw1   8: iw2, dl
-constexpr int TC_CHUNKS_FLAT = 7, TC_CHUNKS_ANY = 9;
+//   0: ax ay   1: s0x s0y   2: s1x s1y   3: uz ruz   4: z0 z1   5: z2 c0   6: g1 g2   7: rbox, blocks | lane << 24, color, tri
+//   (kinds other than FLAT)  8: iw0 iw1   9: iw2, dl
+constexpr int TC_CHUNKS_FLAT = 8, TC_CHUNKS_ANY = 10;
 #ifndef TRGL_TC_BYTES
-#define TRGL_TC_BYTES 1456        // per wave: 13 FLAT slots (10 of the other kinds); with the 8.5 KB depth tile = 10 KB = 16 waves per CU
+#define TRGL_TC_BYTES 1456        // per wave: 11 FLAT slots (9 of the other kinds); with the 8.5 KB depth tile = 10 KB = 16 waves per CU
 #endif
 // Per-wave tile state.
 #ifdef TRGL_DEBUG_COUNTERS
-#define TRGL_DBG(i, n) (S.dbg[i] += (n))
+// counted once per wave whatever lanes are active: the first active lane takes the increment, the lanes are summed at the end
+#define TRGL_DBG(i, n) do { const unsigned long long n_ = (n); if (S.lane == __ffsll((long long)__ballot(1)) - 1) S.dbg[i] += n_; } while (0)
 #else
 #define TRGL_DBG(i, n) ((void)0)
 #endif
 struct TileState {
 #ifdef TRGL_DEBUG_COUNTERS
-    unsigned long long dbg[8];
+    unsigned long long dbg[16];
 #endif
     int lane, px0, py0, xa1, ya0, ya1;
     double lxm, lym;        // (lane&7) + 0.5 - 2^51 and (lane>>3) + 0.5 - 2^51: pixel centre = (2^51 + block origin) + this, exactly
@@ -329,43 +330,57 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
 #ifdef TRGL_DEBUG_COUNTERS
             if (!dropped) TRGL_DBG(1, 1);                                      // blocks visited (the diagnostic build also walks the dropped ones)
 #endif
-            // Stored depth first: every covered pixel of this triangle has z >= T.zbound (see the block-mask comment in
-            // k_raster; -inf for a triangle that is not well scaled) and the z-test is a strict `<`, so a pixel with
-            // zbound >= zold (or zold = NaN) cannot be written whatever its coverage: only lanes that can still win run the
-            // coverage arithmetic, and a block without such a lane costs 8 vector instructions instead of 18.
             // = lds_index(x, y) for an aligned block: row and column of the lane occupy bits 5-7 and 0-2, the row swizzle and 8 cx
             // bits 3-4, 256 cy bits 8-9: the whole index is ONE xor of a per-lane constant with a scalar
             const int li = S.lrow ^ k8;
             const double zold = S.zt[li];
-            const bool alive = act && (T.zbound < zold);
+            // pixel centre (x+0.5, y+0.5), our_gl.cpp:149: (2^51 + bx) + (lx + 0.5 - 2^51) is exact
+            const double pxc = __hiloint2double(0x43200000, bx << 1) + S.lxm;
+            const double pyc = __hiloint2double(0x43200000, by << 1) + S.lym;
+            // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
+            const double s0z = T.ax - pxc, s1z = T.ay - pyc;
+            const double ux = T.s0y * s1z - s0z * T.s1y;                      // geometry.h:145
+            const double uy = s0z * T.s1x - T.s0x * s1z;                      // geometry.h:146
+            const double us = ux + uy;
+            double b0 = 0.0, b1 = 0.0, b2 = 0.0;
+            bool cov;
 #ifdef TRGL_DEBUG_COUNTERS
-            if (!dropped) { if (__ballot(alive) == 0) TRGL_DBG(5, 1); TRGL_DBG(3, __popcll(__ballot(alive))); }   // blocks without a lane that could pass; such lanes
+            bool zkill = false;
+            if (!dropped) TRGL_DBG(3, __popcll(__ballot(act)));                // lanes of visited blocks inside the bbox
 #endif
-            if (alive) {
-                // pixel centre (x+0.5, y+0.5), our_gl.cpp:149: (2^51 + bx) + (lx + 0.5 - 2^51) is exact
-                const double pxc = __hiloint2double(0x43200000, bx << 1) + S.lxm;
-                const double pyc = __hiloint2double(0x43200000, by << 1) + S.lym;
-                // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
-                const double s0z = T.ax - pxc, s1z = T.ay - pyc;
-                const double ux = T.s0y * s1z - s0z * T.s1y;                      // geometry.h:145
-                const double uy = s0z * T.s1x - T.s0x * s1z;                      // geometry.h:146
-                const double us = ux + uy;
-                double b0, b1, b2;
-                bool cov;
-                if (WELL_SCALED) {
-                    // u.z < 0 and nothing can over/underflow, so the signs of the quotients are known
-                    // without dividing: u.y/u.z < 0 <=> u.y > 0, u.x/u.z < 0 <=> u.x > 0, and
-                    // 1 - RN(us/u.z) < 0 <=> RN(us/u.z) > 1 <=> us < u.z  ("exactness").
-                    cov = !(us < uz) && !(uy > 0.0) && !(ux > 0.0);               // :152
-                } else {
+            if (WELL_SCALED) {
+                // Every lane runs the nine coverage operations while the stored depth is on its way from LDS; one branch follows.
+                // u.z < 0 and nothing can over/underflow, so the signs of the quotients are known
+                // without dividing: u.y/u.z < 0 <=> u.y > 0, u.x/u.z < 0 <=> u.x > 0, and
+                // 1 - RN(us/u.z) < 0 <=> RN(us/u.z) > 1 <=> us < u.z  ("exactness").
+                cov = act && !(us < uz) && !(uy > 0.0) && !(ux > 0.0);            // :152
+                // Depth before the divisions.  For a covered pixel 0 <= u.y/u.z, u.x/u.z and us/u.z <= 1 (+ 2^-52), so the z of
+                // :156-158, computed from the three correctly rounded quotients of these same u.x, u.y, us, differs from
+                // z0 + u.y (z1-z0)/u.z + u.x (z2-z0)/u.z by a few 2^-53 max|z_i| (the roundings of the quotients, of 1 - q, of the
+                // three products and two sums); g1, g2 carry three roundings each and the two FMAs two more.  c0 = z0 minus
+                // 2^-40 max|z_i| covers all of it 500 times over: a pixel with c0 + u.y g1 + u.x g2 >= zold fails the strict
+                // z-test of :165 whatever the low bits, and a block whose covered pixels all do skips the three divisions
+                // (43 % of the blocks that used to run them on C4).  NaN reads as "keep"; the batch phase sets c0 = -inf,
+                // g = 0 for a triangle whose plane constants leave the normal range.
+                const double zlow = __builtin_fma(ux, T.g2, __builtin_fma(uy, T.g1, T.c0));
+#ifdef TRGL_DEBUG_COUNTERS
+                zkill = cov && (zlow >= zold);
+#else
+                cov = cov && !(zlow >= zold);
+#endif
+            } else {
+                cov = false;
+                if (act) {
                     b0 = 1.0 - us / uz;                                           // :85, as written
                     b1 = uy / uz;
                     b2 = ux / uz;
                     cov = !(b0 < 0 || b1 < 0 || b2 < 0);                          // :152
                 }
+            }
 #ifdef TRGL_DEBUG_COUNTERS
-                if (!dropped && __ballot(cov)) TRGL_DBG(2, 1);                     // blocks that reach the divisions
+            if (!dropped) { if (__ballot(cov)) TRGL_DBG(2, 1); else TRGL_DBG(5, 1); }   // blocks that reach the divisions / that do not
 #endif
+            {
                 if (cov) {
                 if (WELL_SCALED) {
                     b0 = 1.0 - div_by_uz(us, uz, ruz);
@@ -374,6 +389,16 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                 }
                 const double z = b0 * T.z0 + b1 * T.z1 + b2 * T.z2;           // :156-158
                 // :160 — checked on both paths: the NDC depths of a well-scaled triangle are finite but not bounded
+#ifdef TRGL_DEBUG_COUNTERS
+                if (!dropped) {
+                    const unsigned long long pass = __ballot(__builtin_isfinite(z) && (z < zold));
+                    TRGL_DBG(8, __popcll(__ballot(1)));                       // lanes that run the divisions
+                    TRGL_DBG(9, __popcll(pass));                              // ... and write their pixel
+                    if (!pass) TRGL_DBG(10, 1);                               // blocks that ran the divisions and wrote nothing
+                    if (!__ballot(!zkill)) TRGL_DBG(11, 1);                   // blocks the depth-plane test spares the divisions
+                    TRGL_DBG(12, __popcll(__ballot(zkill && __builtin_isfinite(z) && (z < zold))));   // lanes it would wrongly kill (must be 0)
+                }
+#endif
                 if (__builtin_isfinite(z) && (z < zold)) {                    // :160, :165
                     // PHONG / EYE fragments are not shaded here: the pixel remembers which triangle owns it and k_shade
                     // runs the fragment shader once per visible pixel when the list is done (the shaders have no side
@@ -588,7 +613,7 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     constexpr bool HAS_V = KIND == TRGL_SHADER_GOURAUD;
     TileState S;
 #ifdef TRGL_DEBUG_COUNTERS
-    for (int k = 0; k < 8; ++k) S.dbg[k] = 0;
+    for (int k = 0; k < 16; ++k) S.dbg[k] = 0;
 #endif
     S.lane = lane; S.px0 = px0; S.py0 = py0; S.xa1 = xa1; S.ya0 = ya0; S.ya1 = ya1; S.zt = zt;
     S.bpp = fp.bpp; S.row_bytes = (uint32_t)fp.W * (uint32_t)fp.bpp;
@@ -659,7 +684,6 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
             __builtin_amdgcn_wave_barrier();
         }
         unsigned long long todo;
-        double zbound_l = -__builtin_inf();       // this lane's triangle: lower bound of its covered depths
         uint32_t blocks_l = 0;                    // ... and the aligned 8x8 blocks of the tile its scan has to visit
         uint32_t rbox_l = 0;                      // ... and its clamped bbox relative to the tile origin (TriConst::rbox)
         {
@@ -679,7 +703,6 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
                     const double z2 = __hiloint2double((int)cur.q[5].y, (int)cur.q[5].x);
                     const double zlo = dmin(dmin(z0, z1), z2), zabs = dmax(dmax(fabs(z0), fabs(z1)), fabs(z2));
                     const double zbound = zlo - zabs * 0x1p-40;
-                    zbound_l = zbound;
                     const double ax = __hiloint2double((int)cur.q[0].y, (int)cur.q[0].x), ay = __hiloint2double((int)cur.q[0].w, (int)cur.q[0].z);
                     const double s0x = __hiloint2double((int)cur.q[1].y, (int)cur.q[1].x), s0y = __hiloint2double((int)cur.q[1].w, (int)cur.q[1].z);
                     const double s1x = __hiloint2double((int)cur.q[2].y, (int)cur.q[2].x), s1y = __hiloint2double((int)cur.q[2].w, (int)cur.q[2].z);
@@ -770,11 +793,28 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
             if (mine) {
                 uint4* d = tc + rank * CH;
                 d[0] = cur.q[0]; d[1] = cur.q[1]; d[2] = cur.q[2]; d[3] = cur.q[3]; d[4] = cur.q[4];
-                d[5] = make_uint4(cur.q[5].x, cur.q[5].y, (uint32_t)__double2loint(zbound_l), (uint32_t)__double2hiint(zbound_l));
-                d[6] = make_uint4(rbox_l, blocks_l | ((uint32_t)lane << 24), cur.q[7].z, cur.tri);
+                {   // depth plane of the per-pixel early test (raster_triangle): c0 + u.y g1 + u.x g2 < every covered pixel's z
+                    double c0 = -__builtin_inf(), g1 = 0.0, g2 = 0.0;
+                    if (blocks_l & 0x10000u) {
+                        const double z0 = __hiloint2double((int)cur.q[4].y, (int)cur.q[4].x);
+                        const double z1 = __hiloint2double((int)cur.q[4].w, (int)cur.q[4].z);
+                        const double z2 = __hiloint2double((int)cur.q[5].y, (int)cur.q[5].x);
+                        const double ruz = __hiloint2double((int)cur.q[3].w, (int)cur.q[3].z);
+                        const double zabs = dmax(dmax(fabs(z0), fabs(z1)), fabs(z2));
+                        const double dz1 = z1 - z0, dz2 = z2 - z0;
+                        const double h1 = dz1 * ruz, h2 = dz2 * ruz;
+                        // trusted only while every constant is an ordinary number: |z| < 2^1000, slopes zero (exactly flat) or in [2^-900, 2^1000)
+                        const bool ok = zabs < 0x1p1000 && (dz1 == 0.0 || (fabs(h1) >= 0x1p-900 && fabs(h1) < 0x1p1000)) &&
+                                        (dz2 == 0.0 || (fabs(h2) >= 0x1p-900 && fabs(h2) < 0x1p1000));
+                        if (ok) { c0 = z0 - (zabs * 0x1p-40 + 0x1p-1000); g1 = h1; g2 = h2; }
+                    }
+                    d[5] = make_uint4(cur.q[5].x, cur.q[5].y, (uint32_t)__double2loint(c0), (uint32_t)__double2hiint(c0));
+                    d[6] = make_uint4((uint32_t)__double2loint(g1), (uint32_t)__double2hiint(g1), (uint32_t)__double2loint(g2), (uint32_t)__double2hiint(g2));
+                }
+                d[7] = make_uint4(rbox_l, blocks_l | ((uint32_t)lane << 24), cur.q[7].z, cur.tri);
                 if (!FLAT_ONLY) {
-                    d[7] = make_uint4(cur.q[5].z, cur.q[5].w, cur.q[6].x, cur.q[6].y);
-                    d[8] = make_uint4(cur.q[6].z, cur.q[6].w, cur.q[7].w, 0u);
+                    d[8] = make_uint4(cur.q[5].z, cur.q[5].w, cur.q[6].x, cur.q[6].y);
+                    d[9] = make_uint4(cur.q[6].z, cur.q[6].w, cur.q[7].w, 0u);
                 }
             }
             const unsigned long long round = __ballot(mine);
@@ -784,21 +824,21 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
             for (uint32_t sl = 0; sl < n_round; ++sl) {
                 const uint4* p = tc + sl * CH;                                  // the same address in every lane
                 const double2* pd = reinterpret_cast<const double2*>(p);
-                const double2 d0 = pd[0], d1 = pd[1], d2 = pd[2], d3 = pd[3], d4 = pd[4], d5 = pd[5];
-                const uint4 c6 = p[6];
+                const double2 d0 = pd[0], d1 = pd[1], d2 = pd[2], d3 = pd[3], d4 = pd[4], d5 = pd[5], d6 = pd[6];
+                const uint4 c6 = p[7];
                 TriConst T;
                 T.ax = d0.x; T.ay = d0.y; T.s0x = d1.x; T.s0y = d1.y; T.s1x = d2.x; T.s1y = d2.y;
-                T.uz = d3.x; T.ruz = d3.y; T.z0 = d4.x; T.z1 = d4.y; T.z2 = d5.x; T.zbound = d5.y;
+                T.uz = d3.x; T.ruz = d3.y; T.z0 = d4.x; T.z1 = d4.y; T.z2 = d5.x; T.c0 = d5.y; T.g1 = d6.x; T.g2 = d6.y;
                 T.rbox = (uint32_t)__builtin_amdgcn_readfirstlane((int)c6.x);
                 const uint32_t bw = (uint32_t)__builtin_amdgcn_readfirstlane((int)c6.y);
                 T.blocks = bw & 0xffffu; T.j = bw >> 24;
                 T.color = c6.z; T.tri = c6.w;
                 T.iw0 = T.iw1 = T.iw2 = 0.0; T.dl = 0;
                 if (!FLAT_ONLY) {
-                    const double2 d7 = pd[7];
-                    const uint4 c8 = p[8];
-                    T.iw0 = d7.x; T.iw1 = d7.y; T.iw2 = __hiloint2double((int)c8.y, (int)c8.x);
-                    T.dl = (uint32_t)__builtin_amdgcn_readfirstlane((int)c8.z);
+                    const double2 d8 = pd[8];
+                    const uint4 c9 = p[9];
+                    T.iw0 = d8.x; T.iw1 = d8.y; T.iw2 = __hiloint2double((int)c9.y, (int)c9.x);
+                    T.dl = (uint32_t)__builtin_amdgcn_readfirstlane((int)c9.z);
                 }
                 TRGL_DBG(0, 1);                                                    // list entries rasterized (not skipped)
                 // "well scaled" is a property of the triangle (k_setup leaves ruz = 0 otherwise): wave-uniform by construction
@@ -816,7 +856,8 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     uint32_t frags = S.frags;
     const double zmin = S.zmin, zmax = S.zmax;
 #ifdef TRGL_DEBUG_COUNTERS
-    if (lane == 0) { for (int k = 0; k < 4; ++k) atomicAdd(&stats->dbg[k], S.dbg[k]); atomicAdd(&stats->dbg[5], S.dbg[5]); atomicAdd(&stats->dbg[6], S.dbg[6]); atomicAdd(&stats->dbg[7], S.dbg[7]); atomicAdd(&stats->dbg[4], (unsigned long long)(end - beg)); }
+    for (int k = 0; k < 16; ++k) if (k != 4 && S.dbg[k]) atomicAdd(&stats->dbg[k], S.dbg[k]);
+    if (lane == 0) atomicAdd(&stats->dbg[4], (unsigned long long)(end - beg));
 #endif
 
     // ---- tile out ----------------------------------------------------------------------------

@@ -113,7 +113,7 @@ static int reset_dev_stats(trgl_ctx* c) {
     s.pairs_total = 0;
     s.zero_pos_key = s.zero_neg_key = TRGL_ZERO_KEY_EMPTY;
     s.zero_locked = 0; s.zero_sign = 0;
-    for (int k = 0; k < 8; ++k) s.dbg[k] = 0;
+    for (int k = 0; k < 16; ++k) s.dbg[k] = 0;
     *c->stats_pinned = s;
     HIPCHK(c, hipMemcpyAsync(c->stats_dev, c->stats_pinned, sizeof(DevStats), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -826,11 +826,11 @@ int trgl_reset_phase_ms(trgl_ctx* c) {
     return TRGL_OK;
 }
 // diagnostic builds (-DTRGL_DEBUG_COUNTERS): k_raster work counters since the last stats reset
-extern "C" int trgl_debug_counters(trgl_ctx* c, unsigned long long out[8]) {
+extern "C" int trgl_debug_counters(trgl_ctx* c, unsigned long long out[16]) {
     CHKCTX(c);
     int r = flush_sync(c); if (r) return r;
     HIPCHK(c, hipMemcpy(c->stats_pinned, c->stats_dev, sizeof(DevStats), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 8; ++k) out[k] = c->stats_pinned->dbg[k];
+    for (int k = 0; k < 16; ++k) out[k] = c->stats_pinned->dbg[k];
     return TRGL_OK;
 }
 

@@ -63,7 +63,7 @@ struct DevStats {
     // order (triangle, x, y).  Keys = tri<<32 | x<<16 | y of the first +0 / -0 fragment of this flush.
     unsigned long long zero_pos_key, zero_neg_key;
     uint32_t zero_locked, zero_sign;     // set by k_fold_stats once any zero has been written
-    unsigned long long dbg[8];           // diagnostic builds only (-DTRGL_DEBUG_COUNTERS): work counters of k_raster
+    unsigned long long dbg[16];           // diagnostic builds only (-DTRGL_DEBUG_COUNTERS): work counters of k_raster
 };
 #define TRGL_ZERO_KEY_EMPTY 0xffffffffffffffffull
 
