@@ -12,8 +12,13 @@ L.trgl_draw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
 assert L.trgl_draw(h, 0, None, dclip.data_ptr(), None, dcol.data_ptr(), N, 1) == 0
 out = (C.c_ulonglong * 16)(); L.trgl_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
 assert L.trgl_debug_counters(h, out) == 0
-names = ["triangles scanned (slots read)", "blocks visited", "blocks reaching the divisions", "lanes of visited blocks inside the bbox", "list entries (pairs)",
-         "visited blocks that skip the divisions", "blocks dropped by the per-lane masks", "... of which wrote a pixel (must be 0)",
-         "lanes that ran the divisions", "... and wrote their pixel", "blocks that ran the divisions and wrote nothing",
-         "blocks the depth-plane test spares the divisions", "lanes it would wrongly kill (must be 0)"]
-for n, v in zip(names, out): print(f"{n:44s} {v:>12d}  per triangle {v / N:.3f}")
+names = ["triangles scanned (slots read)", "blocks visited", "blocks with a covered pixel inside the bbox (before the depth-plane test)",
+         "lanes of visited blocks inside the bbox", "list entries (pairs)", "visited blocks without a covered pixel",
+         "blocks dropped by the per-lane masks", "... of which wrote a pixel (must be 0)",
+         "covered lanes (before the depth-plane test)", "... that write their pixel", "blocks with covered pixels that write nothing",
+         "... of which the depth-plane test spares the divisions", "lanes the depth-plane test would wrongly kill (must be 0)",
+         "blocks an ideal per-4x4-cell depth test would also drop (bound for finer masks)", "blocks with covered pixels, all behind the stored depth"]
+for n, v in zip(names, out): print(f"{n:82s} {v:>12d}  per triangle {v / N:.3f}")
+# the diagnostic build counts what the depth-plane test WOULD skip and still runs it; the production kernel:
+print(f"{'production kernel: blocks that run the three divisions':82s} {out[2] - out[11]:>12d}  per triangle {(out[2] - out[11]) / N:.3f}")
+print(f"{'production kernel: visited blocks that end before the divisions':82s} {out[1] - out[2] + out[11]:>12d}  per triangle {(out[1] - out[2] + out[11]) / N:.3f}")

@@ -271,13 +271,14 @@ constexpr int TC_CHUNKS_FLAT = 8, TC_CHUNKS_ANY = 10;
 #else
 #define TRGL_DBG(i, n) ((void)0)
 #endif
+typedef __attribute__((address_space(3))) double lds_f64;
 struct TileState {
 #ifdef TRGL_DEBUG_COUNTERS
     unsigned long long dbg[16];
 #endif
     int lane, px0, py0, xa1, ya0, ya1;
     double lxm, lym;        // (lane&7) + 0.5 - 2^51 and (lane>>3) + 0.5 - 2^51: pixel centre = (2^51 + block origin) + this, exactly
-    int lrow;               // the lane's part of lds_index() inside an aligned block: (lane>>3)*32 + (lane&7) + (((lane>>3)&3)<<3)
+    uint32_t laddr;         // LDS byte address of the lane's pixel of block 0: tile base + 8 * ((lane>>3)*32 + (lane&7) + (((lane>>3)&3)<<3)), see lds_index()
     double* zt;
     uint8_t* fb_lane;       // address of this lane's pixel of block 0 in the framebuffer (colours are written straight to it)
     int bpp; uint32_t row_bytes;   // framebuffer bytes per pixel / per row
@@ -318,7 +319,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
             const int k = __builtin_ctz(m);
             m &= m - 1;
             const int cx = k & 3, cy = k >> 2;
-            const int k8 = (8 * cx) | (256 * cy);                             // wave-uniform
+            const int k8 = (8 * cx) | (256 * cy);                             // wave-uniform: the block's offset in lds_index() units
 #ifdef TRGL_DEBUG_COUNTERS
             const bool dropped = !((T.blocks >> k) & 1u);
             if (dropped) TRGL_DBG(6, 1);
@@ -332,8 +333,10 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
 #endif
             // = lds_index(x, y) for an aligned block: row and column of the lane occupy bits 5-7 and 0-2, the row swizzle and 8 cx
             // bits 3-4, 256 cy bits 8-9: the whole index is ONE xor of a per-lane constant with a scalar
-            const int li = S.lrow ^ k8;
-            const double zold = S.zt[li];
+            uint32_t k8b = (uint32_t)k8 << 3;
+            asm("" : "+s"(k8b));                                              // one scalar, one v_xor (the compiler would split it into a three-operand xor plus a move)
+            const uint32_t la = S.laddr ^ k8b;
+            const double zold = *(lds_f64*)(uintptr_t)la;
             // pixel centre (x+0.5, y+0.5), our_gl.cpp:149: (2^51 + bx) + (lx + 0.5 - 2^51) is exact
             const double pxc = __hiloint2double(0x43200000, bx << 1) + S.lxm;
             const double pyc = __hiloint2double(0x43200000, by << 1) + S.lym;
@@ -365,6 +368,15 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                 const double zlow = __builtin_fma(ux, T.g2, __builtin_fma(uy, T.g1, T.c0));
 #ifdef TRGL_DEBUG_COUNTERS
                 zkill = cov && (zlow >= zold);
+                if (!dropped) {
+                    // what a test per 4x4-pixel cell could do at best: a lane survives if its plane value is below the largest
+                    // stored depth of ITS cell (the block-level masks compare the plane minimum with the block's maximum)
+                    double cm = zold;
+                    cm = dmax(cm, __shfl_xor(cm, 1)); cm = dmax(cm, __shfl_xor(cm, 2));
+                    cm = dmax(cm, __shfl_xor(cm, 8)); cm = dmax(cm, __shfl_xor(cm, 16));
+                    if (__ballot(cov) && !__ballot(cov && (zlow < cm))) TRGL_DBG(13, 1);
+                    if (__ballot(cov && !zkill) == 0 && __ballot(cov)) TRGL_DBG(14, 1);
+                }
 #else
                 cov = cov && !(zlow >= zold);
 #endif
@@ -436,7 +448,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
 #ifdef TRGL_DEBUG_COUNTERS
                     if (dropped) TRGL_DBG(7, 1);                              // must stay 0
 #endif
-                    S.zt[li] = z;                                             // :191
+                    *(lds_f64*)(uintptr_t)la = z;                                        // :191
                     if (!shade_later) {                                       // :192, tgaimage.cpp:32-39: straight to the framebuffer
                         // the block's offset from block 0 fits 32 bits (24 rows x < 2^18 bytes): scalar arithmetic, one 64-bit add per lane
                         uint8_t* dst = S.fb_lane + (uint32_t)((uint32_t)(8 * cy) * S.row_bytes + (uint32_t)(8 * cx) * (uint32_t)S.bpp);
@@ -533,7 +545,8 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
                                                 const DevTexture* __restrict__ tex, DevStats* __restrict__ stats,
                                                 const uint32_t* __restrict__ items, const uint32_t* __restrict__ n_items,
                                                 unsigned long long* __restrict__ item_stats) {
-    __shared__ __attribute__((aligned(16))) double   s_z[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
+    // 8 KB per wave, first in the block's LDS and 8 KB-aligned: a block's offset inside a wave's depth tile is XORed into the lane's byte address
+    __shared__ __attribute__((aligned(8192))) double s_z[TRGL_WAVES_PER_BLOCK][TRGL_TILE_PIX];
     __shared__ double s_hz[TRGL_WAVES_PER_BLOCK][64];    // depth maxima of the 64 4x4-pixel cells of the tile
     __shared__ __attribute__((aligned(16))) uint4 s_tc[TRGL_WAVES_PER_BLOCK][TRGL_TC_BYTES / 16];   // scan constants of a batch's surviving triangles
 
@@ -621,7 +634,7 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     S.row_px = (uint32_t)fp.W;
     S.id_lane = DEFERRED ? fp.idbuf + ((size_t)(py0 + (lane >> 3)) * fp.W + (size_t)(px0 + (lane & 7))) : nullptr;
     S.lxm = ((double)(lane & 7) + 0.5) - 0x1p51; S.lym = ((double)(lane >> 3) + 0.5) - 0x1p51;
-    S.lrow = ((lane >> 3) * 32 + (lane & 7)) | (((lane >> 3) & 3) << 3);
+    S.laddr = (uint32_t)(uintptr_t)(lds_f64*)zt + 8u * (uint32_t)(((lane >> 3) * 32 + (lane & 7)) | (((lane >> 3) & 3) << 3));
     S.frags = 0; S.zmin = __builtin_inf(); S.zmax = -__builtin_inf();
     S.zero_locked = stats->zero_locked != 0;
 
