@@ -560,6 +560,26 @@ def test_pair_buffers_grow_behind_an_optimistic_launch():
         assert np.array_equal(fb, o.fb) and np.array_equal(z.view(np.uint64), o.z.view(np.uint64)) and st == o.stats
 
 
+def test_frames_beyond_65536_tiles_use_wide_keys():
+    """The binning sorts 16-bit tile indices while the frame has at most 65536 tiles (8192x8192 is exactly that) and 32-bit
+    ones beyond: 8224x8224 = 257x257 tiles, with triangles in the last tile rows (indices above 65535 would wrap)."""
+    W = H = 8224
+    n = 3000
+    clip, col = scenes.random_triangles(n, W, H, seed=4242, rmin=4, rmax=60)
+    clip = clip.copy()
+    clip[: n // 2, [1, 5, 9]] = clip[: n // 2, [1, 5, 9]] * 0.02 + 0.975 * clip[: n // 2, [3, 7, 11]]     # half of them into the top rows (NDC y near +1)
+    with Context(W, H, 3) as ctx:
+        ctx.draw(FLAT, clip, colors=col)
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    o = orc.Oracle(W, H, 3)
+    o.draw(orc.FLAT, clip, colors=col)
+    assert st == o.stats
+    assert np.array_equal(z.view(np.uint64), o.z.view(np.uint64))
+    assert np.array_equal(fb, o.fb)
+    ys = np.nonzero(np.isfinite(z).any(axis=1))[0]
+    assert ys.max() >= 8192 or ys.min() < 32          # the frame's extreme tile rows were hit (whichever way y is flipped)
+
+
 def test_more_than_2_to_32_pairs_is_refused_not_wrapped():
     """70 000 full-screen triangles at 8192x8192 are 4.6e9 (tile, triangle) pairs: the pair count is accumulated in 64 bits
     on the device (k_chunk_spine), every binning kernel sees it exceed the buffers and does nothing, and the flush returns

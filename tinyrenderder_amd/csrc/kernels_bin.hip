@@ -334,12 +334,20 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_chunk_spine(const uint32_t* _
 
 // expand: triangle i owns pairs [off, off + cnt[i]) = its tiles in row-major order; off is computed here.
 // Triangles with many tiles are written by the whole wave.  One launch per draw (same blocks as k_setup).
+// The pairs of a block are consecutive in the output (the offsets are a prefix sum in submission order), so they are
+// assembled in LDS and written out linearly: whole cache lines instead of 64 lanes x a few elements each with a stride.
+// A block whose triangles cover more than EXPAND_STAGE tiles writes straight to memory.
+// K: the key type, 16 bits while the frame has at most 65536 tiles (up to 8192x8192), 32 bits beyond.
+constexpr uint32_t EXPAND_STAGE = 3072;
+template <typename K>
 __global__ __launch_bounds__(256) void k_expand(FrameParams fp, uint32_t first, uint32_t n, int tiles_x, const uint32_t* __restrict__ cnt,
                                                 const uint32_t* __restrict__ blk_sums, const uint32_t* __restrict__ chunk_off,
                                                 uint32_t blk_base, const uint2* __restrict__ tilebox,
-                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                K* __restrict__ keys, uint32_t* __restrict__ vals,
                                                 const unsigned long long* __restrict__ pairs_total, uint32_t cap) {
     __shared__ uint32_t smem[4];
+    __shared__ uint32_t s_v[EXPAND_STAGE];
+    __shared__ K s_k[EXPAND_STAGE];
     if (*pairs_total > cap) return;        // the host sized the buffers from an earlier flush: it will grow them and launch again
     const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = first + local;                          // index of the triangle within the flush
@@ -349,14 +357,17 @@ __global__ __launch_bounds__(256) void k_expand(FrameParams fp, uint32_t first, 
     uint32_t base = chunk_off[blk / EXPAND_CHUNK];
     for (uint32_t q = blk - blk % EXPAND_CHUNK; q < blk; ++q) base += blk_sums[q];      // wave-uniform loads
     uint32_t tot;
-    const uint32_t o = base + block_excl_scan(c, smem, &tot);
+    const uint32_t o = block_excl_scan(c, smem, &tot);         // offset inside the block's run of pairs
+    const bool staged = tot <= EXPAND_STAGE;                   // block-uniform
+    K* const kdst = keys + base; uint32_t* const vdst = vals + base;
     constexpr uint32_t SMALL = 8;
     if (c && c <= SMALL) {
         uint32_t tx0 = tb.x & 0xffff, ty0 = tb.x >> 16, tx1 = tb.y & 0xffff;
         uint32_t wdt = tx1 - tx0 + 1;
         for (uint32_t k = 0; k < c; ++k) {
             uint32_t ty = fp.il_tiles ? (uint32_t)il_nth_owned_from(fp, (int)ty0, (int)(k / wdt)) : ty0 + k / wdt, tx = tx0 + k % wdt;
-            keys[o + k] = ty * tiles_x + tx; vals[o + k] = i;
+            const K key = (K)(ty * tiles_x + tx);
+            if (staged) { s_k[o + k] = key; s_v[o + k] = i; } else { kdst[o + k] = key; vdst[o + k] = i; }
         }
     }
     unsigned long long big = __ballot(c > SMALL);
@@ -370,8 +381,13 @@ __global__ __launch_bounds__(256) void k_expand(FrameParams fp, uint32_t first, 
         uint32_t wdt = tx1 - tx0 + 1;
         for (uint32_t k = lane; k < cc; k += 64) {
             uint32_t ty = fp.il_tiles ? (uint32_t)il_nth_owned_from(fp, (int)ty0, (int)(k / wdt)) : ty0 + k / wdt, tx = tx0 + k % wdt;
-            keys[oo + k] = ty * tiles_x + tx; vals[oo + k] = ii;
+            const K key = (K)(ty * tiles_x + tx);
+            if (staged) { s_k[oo + k] = key; s_v[oo + k] = ii; } else { kdst[oo + k] = key; vdst[oo + k] = ii; }
         }
+    }
+    if (staged) {
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < tot; j += 256) { kdst[j] = s_k[j]; vdst[j] = s_v[j]; }
     }
 }
 
@@ -388,7 +404,19 @@ constexpr int RADIX_WAVE_CHUNK = RADIX_CHUNK / 4;
 constexpr int RADIX_ROUNDS = RADIX_WAVE_CHUNK / 64;      // 16
 constexpr int RADIX_MAX_BITS = 8;
 
-__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ pairs_total,
+// four consecutive keys with one load (the pair buffers hold a multiple of 4 entries and p is a multiple of 4)
+template <typename K> __device__ __forceinline__ void load4(const K* __restrict__ keys, uint64_t p, uint32_t k[4]);
+template <> __device__ __forceinline__ void load4<uint32_t>(const uint32_t* __restrict__ keys, uint64_t p, uint32_t k[4]) {
+    const uint4 q = *reinterpret_cast<const uint4*>(keys + p);
+    k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
+}
+template <> __device__ __forceinline__ void load4<uint16_t>(const uint16_t* __restrict__ keys, uint64_t p, uint32_t k[4]) {
+    const uint2 q = *reinterpret_cast<const uint2*>(keys + p);
+    k[0] = q.x & 0xffffu; k[1] = q.x >> 16; k[2] = q.y & 0xffffu; k[3] = q.y >> 16;
+}
+
+template <typename K>
+__global__ __launch_bounds__(256) void k_radix_hist(const K* __restrict__ keys, const unsigned long long* __restrict__ pairs_total,
                                                     uint32_t cap, int shift, int bits,
                                                     uint32_t nblocks, uint32_t* __restrict__ hist) {
     __shared__ uint32_t s_cnt[1 << RADIX_MAX_BITS];
@@ -399,20 +427,27 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__
     __syncthreads();
     const uint64_t beg = (uint64_t)blockIdx.x * RADIX_CHUNK;
     uint64_t end = beg + RADIX_CHUNK; if (end > P) end = P;      // blocks past the last pair (the grid covers the capacity) add zeros
-    for (uint64_t p = beg + threadIdx.x; p < end; p += 256) atomicAdd(&s_cnt[(keys[p] >> shift) & mask], 1u);
+    for (uint64_t p = beg + 4u * threadIdx.x; p < end; p += 1024) {
+        uint32_t k[4];
+        load4<K>(keys, p, k);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (p + q < end) atomicAdd(&s_cnt[(k[q] >> shift) & mask], 1u);
+    }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nb; b += 256) hist[(size_t)b * nblocks + blockIdx.x] = s_cnt[b];
 }
 
-__global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+template <typename K>
+__global__ __launch_bounds__(256) void k_radix_scatter(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        const unsigned long long* __restrict__ pairs_total, uint32_t cap,
                                                        int shift, int bits, uint32_t nblocks,
                                                        const uint32_t* __restrict__ base,
-                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+                                                       K* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
     __shared__ uint32_t s_cnt[4][1 << RADIX_MAX_BITS];     // per wave: running count, then (after phase 2) local start
     __shared__ uint32_t s_start[1 << RADIX_MAX_BITS];      // first local position of each digit in the chunk
     __shared__ uint32_t s_gbase[1 << RADIX_MAX_BITS];      // global position of the chunk's first pair of each digit
-    __shared__ uint32_t s_key[RADIX_CHUNK], s_val[RADIX_CHUNK];
+    __shared__ uint32_t s_val[RADIX_CHUNK];
+    __shared__ K s_key[RADIX_CHUNK];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned long long P64 = *pairs_total;
     const uint32_t P = P64 > cap ? 0u : (uint32_t)P64;
@@ -435,7 +470,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
     for (int r = 0; r < RADIX_ROUNDS; ++r) {
         const uint64_t p = wbeg + (uint64_t)r * 64 + lane;
         const bool act = p < cend;
-        k[r] = act ? keys_in[p] : 0; v[r] = act ? vals_in[p] : 0;
+        k[r] = act ? (uint32_t)keys_in[p] : 0; v[r] = act ? vals_in[p] : 0;
     }
 #pragma unroll
     for (int r = 0; r < RADIX_ROUNDS; ++r) {
@@ -483,7 +518,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
         if (wbeg + (uint64_t)r * 64 + lane < cend) {
             const uint32_t dgt = (k[r] >> shift) & mask;
             const uint32_t lp = s_cnt[w][dgt] + rk[r];
-            s_key[lp] = k[r]; s_val[lp] = v[r];
+            s_key[lp] = (K)k[r]; s_val[lp] = v[r];
         }
     }
     __syncthreads();
@@ -492,21 +527,22 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
         const uint32_t key = s_key[i];
         const uint32_t dgt = (key >> shift) & mask;
         const uint32_t dst = s_gbase[dgt] + (i - s_start[dgt]);
-        keys_out[dst] = key; vals_out[dst] = s_val[i];
+        keys_out[dst] = (K)key; vals_out[dst] = s_val[i];
     }
 }
 
-// per-tile slice [start, end) of the sorted pair list: four consecutive pairs per thread (one 16-byte load)
-__global__ __launch_bounds__(256) void k_bounds(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ pairs_total, uint32_t cap,
+// per-tile slice [start, end) of the sorted pair list: four consecutive pairs per thread (one load)
+template <typename K>
+__global__ __launch_bounds__(256) void k_bounds(const K* __restrict__ keys, const unsigned long long* __restrict__ pairs_total, uint32_t cap,
                                                 uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_end) {
     const unsigned long long P64 = *pairs_total;
     const uint32_t P = P64 > cap ? 0u : (uint32_t)P64;
     const uint32_t p0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
     if (p0 >= P) return;
-    const uint4 q = *reinterpret_cast<const uint4*>(keys + p0);          // the buffers hold a multiple of 4 entries (grow_pairs)
-    const uint32_t k[4] = { q.x, q.y, q.z, q.w };
-    uint32_t prev = p0 ? keys[p0 - 1] : 0u;
-    const uint32_t after = (p0 + 4 < P) ? keys[p0 + 4] : 0u;
+    uint32_t k[4];
+    load4<K>(keys, p0, k);                                              // the buffers hold a multiple of 4 entries (grow_pairs)
+    uint32_t prev = p0 ? (uint32_t)keys[p0 - 1] : 0u;
+    const uint32_t after = (p0 + 4 < P) ? (uint32_t)keys[p0 + 4] : 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t p = p0 + (uint32_t)i;
@@ -554,32 +590,44 @@ void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uin
 }
 
 void launch_expand(hipStream_t s, const FrameParams& fp, uint32_t first, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* blk_sums,
-                   const uint32_t* chunk_off, uint32_t blk_base, const uint2* tilebox, uint32_t* keys, uint32_t* vals,
+                   const uint32_t* chunk_off, uint32_t blk_base, const uint2* tilebox, void* keys, bool key16, uint32_t* vals,
                    const unsigned long long* pairs_total, uint32_t cap) {
     if (!n) return;
-    hipLaunchKernelGGL(k_expand, dim3(setup_num_blocks(n)), dim3(SETUP_THREADS), 0, s, fp, first, n, tiles_x, cnt, blk_sums, chunk_off,
-                       blk_base, tilebox, keys, vals, pairs_total, cap);
+    if (key16)
+        hipLaunchKernelGGL(k_expand<uint16_t>, dim3(setup_num_blocks(n)), dim3(SETUP_THREADS), 0, s, fp, first, n, tiles_x, cnt, blk_sums, chunk_off,
+                           blk_base, tilebox, (uint16_t*)keys, vals, pairs_total, cap);
+    else
+        hipLaunchKernelGGL(k_expand<uint32_t>, dim3(setup_num_blocks(n)), dim3(SETUP_THREADS), 0, s, fp, first, n, tiles_x, cnt, blk_sums, chunk_off,
+                           blk_base, tilebox, (uint32_t*)keys, vals, pairs_total, cap);
 }
 
 uint32_t radix_num_workers(uint32_t P) { return (P + RADIX_CHUNK - 1) / RADIX_CHUNK; }   // = blocks of a pass
 
 // The pair count of the flush stays on the device (`pairs_total`): grids cover `cap`, the capacity of the pair buffers,
 // and blocks past the last pair do nothing, so the host never has to wait for the count before it can queue these.
-void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
-                       uint32_t* vals_out, const unsigned long long* pairs_total, uint32_t cap, int shift, int bits,
-                       uint32_t* hist, uint32_t* scan_tmp) {
-    if (!cap) return;
+template <typename K>
+static void radix_pass_t(hipStream_t s, const K* keys_in, const uint32_t* vals_in, K* keys_out, uint32_t* vals_out,
+                         const unsigned long long* pairs_total, uint32_t cap, int shift, int bits, uint32_t* hist, uint32_t* scan_tmp) {
     uint32_t nblk = radix_num_workers(cap);
-    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(256), 0, s, keys_in, pairs_total, cap, shift, bits, nblk, hist);
+    hipLaunchKernelGGL(k_radix_hist<K>, dim3(nblk), dim3(256), 0, s, keys_in, pairs_total, cap, shift, bits, nblk, hist);
     launch_exclusive_scan(s, hist, hist, (uint64_t)nblk << bits, scan_tmp, nullptr);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(256), 0, s, keys_in, vals_in, pairs_total, cap, shift, bits, nblk, hist,
+    hipLaunchKernelGGL(k_radix_scatter<K>, dim3(nblk), dim3(256), 0, s, keys_in, vals_in, pairs_total, cap, shift, bits, nblk, hist,
                        keys_out, vals_out);
 }
 
-void launch_bounds(hipStream_t s, const uint32_t* keys, const unsigned long long* pairs_total, uint32_t cap,
+void launch_radix_pass(hipStream_t s, const void* keys_in, const uint32_t* vals_in, void* keys_out,
+                       uint32_t* vals_out, bool key16, const unsigned long long* pairs_total, uint32_t cap, int shift, int bits,
+                       uint32_t* hist, uint32_t* scan_tmp) {
+    if (!cap) return;
+    if (key16) radix_pass_t<uint16_t>(s, (const uint16_t*)keys_in, vals_in, (uint16_t*)keys_out, vals_out, pairs_total, cap, shift, bits, hist, scan_tmp);
+    else radix_pass_t<uint32_t>(s, (const uint32_t*)keys_in, vals_in, (uint32_t*)keys_out, vals_out, pairs_total, cap, shift, bits, hist, scan_tmp);
+}
+
+void launch_bounds(hipStream_t s, const void* keys, bool key16, const unsigned long long* pairs_total, uint32_t cap,
                    uint32_t* tile_start, uint32_t* tile_end) {
     if (!cap) return;
-    hipLaunchKernelGGL(k_bounds, dim3((cap + 1023) / 1024), dim3(256), 0, s, keys, pairs_total, cap, tile_start, tile_end);
+    if (key16) hipLaunchKernelGGL(k_bounds<uint16_t>, dim3((cap + 1023) / 1024), dim3(256), 0, s, (const uint16_t*)keys, pairs_total, cap, tile_start, tile_end);
+    else hipLaunchKernelGGL(k_bounds<uint32_t>, dim3((cap + 1023) / 1024), dim3(256), 0, s, (const uint32_t*)keys, pairs_total, cap, tile_start, tile_end);
 }
 
 }  // namespace trgl

@@ -18,15 +18,16 @@ void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uin
 // expand / radix / bounds read the flush's pair count from device memory and cover `cap` (the capacity of the pair buffers)
 // with their grids; they do nothing when the count exceeds it (the host then grows the buffers and queues them again)
 void launch_expand(hipStream_t s, const FrameParams& fp, uint32_t first, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* blk_sums,
-                   const uint32_t* chunk_off, uint32_t blk_base, const uint2* tilebox, uint32_t* keys, uint32_t* vals,
+                   const uint32_t* chunk_off, uint32_t blk_base, const uint2* tilebox, void* keys, bool key16, uint32_t* vals,
                    const unsigned long long* pairs_total, uint32_t cap);
 
 uint32_t radix_num_workers(uint32_t P);
-void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
-                       uint32_t* vals_out, const unsigned long long* pairs_total, uint32_t cap, int shift, int bits,
+// key16: the keys (tile indices) are 16-bit words (frames of at most 65536 tiles), else 32-bit
+void launch_radix_pass(hipStream_t s, const void* keys_in, const uint32_t* vals_in, void* keys_out,
+                       uint32_t* vals_out, bool key16, const unsigned long long* pairs_total, uint32_t cap, int shift, int bits,
                        uint32_t* hist, uint32_t* scan_tmp);
 
-void launch_bounds(hipStream_t s, const uint32_t* keys, const unsigned long long* pairs_total, uint32_t cap,
+void launch_bounds(hipStream_t s, const void* keys, bool key16, const unsigned long long* pairs_total, uint32_t cap,
                    uint32_t* tile_start, uint32_t* tile_end);
 
 uint32_t owned_tiles(const FrameParams& fp);       // tiles of the rows this context owns (strip or interleaved bands)

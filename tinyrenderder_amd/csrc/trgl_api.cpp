@@ -438,8 +438,9 @@ static int queue_binning(trgl_ctx* c, const FrameParams& fp, uint32_t cap, int* 
     const unsigned long long* pairs_dev = &c->stats_dev->pairs_total;
     int r;
     uint32_t blk_base = 0;
+    const bool key16 = ntiles <= 65536;        // tile indices as 16-bit keys: a third less traffic in every binning kernel
     for (auto& d : c->draws) {
-        launch_expand(s, fp, d.first, d.n, c->tiles_x, c->cnt, c->blk_sums, c->chunk_off, blk_base, c->tilebox, c->keys[0], c->vals[0], pairs_dev, cap);
+        launch_expand(s, fp, d.first, d.n, c->tiles_x, c->cnt, c->blk_sums, c->chunk_off, blk_base, c->tilebox, c->keys[0], key16, c->vals[0], pairs_dev, cap);
         blk_base += setup_num_blocks(d.n);
     }
     int key_bits = 1; while ((size_t(1) << key_bits) < ntiles) ++key_bits;
@@ -450,11 +451,11 @@ static int queue_binning(trgl_ctx* c, const FrameParams& fp, uint32_t cap, int* 
     if ((r = grow(c, c->scan_tmp, c->cap_scan, (size_t)scan_num_blocks(hist_need) + 16))) return r;
     int cur = 0;
     for (int ps = 0; ps < passes; ++ps) {
-        launch_radix_pass(s, c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1], pairs_dev, cap, ps * bits_per, bits_per,
+        launch_radix_pass(s, c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1], key16, pairs_dev, cap, ps * bits_per, bits_per,
                           c->hist, c->scan_tmp);
         cur ^= 1;
     }
-    launch_bounds(s, c->keys[cur], pairs_dev, cap, c->tile_start, c->tile_end);
+    launch_bounds(s, c->keys[cur], key16, pairs_dev, cap, c->tile_start, c->tile_end);
     *cur_out = cur;
     return TRGL_OK;
 }
