@@ -16,8 +16,8 @@ names = ["triangles scanned (slots read)", "blocks visited", "blocks with a cove
          "lanes of visited blocks inside the bbox", "list entries (pairs)", "visited blocks without a covered pixel",
          "blocks dropped by the per-lane masks", "... of which wrote a pixel (must be 0)",
          "covered lanes (before the depth-plane test)", "... that write their pixel", "blocks with covered pixels that write nothing",
-         "... of which the depth-plane test spares the divisions", "lanes the depth-plane test would wrongly kill (must be 0)",
-         "blocks an ideal per-4x4-cell depth test would also drop (bound for finer masks)", "blocks with covered pixels, all behind the stored depth"]
+         "... of which the per-pixel depth-plane test ends before the coverage arithmetic", "lanes the depth-plane test would wrongly kill (must be 0)"
+         ]
 for n, v in zip(names, out): print(f"{n:82s} {v:>12d}  per triangle {v / N:.3f}")
 # the diagnostic build counts what the depth-plane test WOULD skip and still runs it; the production kernel:
 print(f"{'production kernel: blocks that run the three divisions':82s} {out[2] - out[11]:>12d}  per triangle {(out[2] - out[11]) / N:.3f}")

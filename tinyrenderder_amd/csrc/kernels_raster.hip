@@ -251,7 +251,7 @@ __device__ __forceinline__ double div_by_uz(double a, double uz, double ruz) {
 // Only the three words that steer control flow are made wave-uniform (v_readfirstlane).
 struct TriConst {
     double ax, ay, s0x, s0y, s1x, s1y, uz, ruz, z0, z1, z2, iw0, iw1, iw2;
-    double c0, g1, g2;  // depth plane for the per-pixel early test: every covered pixel has z > c0 + u.y g1 + u.x g2 (c0 = -inf: no test)
+    double c0, g1, g2;  // depth plane for the per-pixel early test: every covered pixel has z > c0 + (ax-x) g1 + (ay-y) g2 (c0 = -inf: no test)
     uint32_t color, dl, tri;    // per-lane copies
     uint32_t rbox;      // SGPR: rx0 | ry0<<8 | (rx1-rx0)<<16 | (ry1-ry0)<<24, the clamped bbox relative to the tile origin
     uint32_t blocks;    // SGPR: bit k set: the aligned 8x8 block k of the tile may hold covered pixels that pass the z-test
@@ -342,47 +342,34 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
             const double pyc = __hiloint2double(0x43200000, by << 1) + S.lym;
             // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
             const double s0z = T.ax - pxc, s1z = T.ay - pyc;
-            const double ux = T.s0y * s1z - s0z * T.s1y;                      // geometry.h:145
-            const double uy = s0z * T.s1x - T.s0x * s1z;                      // geometry.h:146
-            const double us = ux + uy;
-            double b0 = 0.0, b1 = 0.0, b2 = 0.0;
-            bool cov;
+            // Depth first, per pixel.  The z of :156-158 is the plane z0 + (s0z Gx + s1z Gy) / u.z through the three vertices
+            // [Gx = s1x (z1-z0) - s1y (z2-z0), Gy = s0y (z2-z0) - s0x (z1-z0)] up to the roundings of u.x, u.y, the three quotients
+            // and the weighted sum: at most 2^-50 max|z_i| (R S/|u.z| + 1) for a covered pixel (k_raster, block masks).  g1 = Gx/u.z and
+            // g2 = Gy/u.z carry a few more roundings of the same size, and c0 = z0 minus 2^-40 max|z_i| (R S/|u.z| + 1) covers all of
+            // it a thousand times over: a pixel with c0 + s0z g1 + s1z g2 >= zold fails the strict z-test of :165 whatever its
+            // coverage and the low bits of its z, so only lanes that can still win run the coverage arithmetic, and a block without
+            // one (47 % of the visited blocks on C4) ends here.  NaN reads as "keep"; c0 = -inf, g = 0 for a triangle that is not
+            // well scaled or whose plane constants leave the normal range.
+            const double zpl = __builtin_fma(s0z, T.g1, __builtin_fma(s1z, T.g2, T.c0));
 #ifdef TRGL_DEBUG_COUNTERS
-            bool zkill = false;
+            const bool zkill = act && (zpl >= zold);
+            const bool alive = act;
             if (!dropped) TRGL_DBG(3, __popcll(__ballot(act)));                // lanes of visited blocks inside the bbox
-#endif
-            if (WELL_SCALED) {
-                // Every lane runs the nine coverage operations while the stored depth is on its way from LDS; one branch follows.
-                // u.z < 0 and nothing can over/underflow, so the signs of the quotients are known
-                // without dividing: u.y/u.z < 0 <=> u.y > 0, u.x/u.z < 0 <=> u.x > 0, and
-                // 1 - RN(us/u.z) < 0 <=> RN(us/u.z) > 1 <=> us < u.z  ("exactness").
-                cov = act && !(us < uz) && !(uy > 0.0) && !(ux > 0.0);            // :152
-                // Depth before the divisions.  For a covered pixel 0 <= u.y/u.z, u.x/u.z and us/u.z <= 1 (+ 2^-52), so the z of
-                // :156-158, computed from the three correctly rounded quotients of these same u.x, u.y, us, differs from
-                // z0 + u.y (z1-z0)/u.z + u.x (z2-z0)/u.z by a few 2^-53 max|z_i| (the roundings of the quotients, of 1 - q, of the
-                // three products and two sums); g1, g2 carry three roundings each and the two FMAs two more.  c0 = z0 minus
-                // 2^-40 max|z_i| covers all of it 500 times over: a pixel with c0 + u.y g1 + u.x g2 >= zold fails the strict
-                // z-test of :165 whatever the low bits, and a block whose covered pixels all do skips the three divisions
-                // (43 % of the blocks that used to run them on C4).  NaN reads as "keep"; the batch phase sets c0 = -inf,
-                // g = 0 for a triangle whose plane constants leave the normal range.
-                const double zlow = __builtin_fma(ux, T.g2, __builtin_fma(uy, T.g1, T.c0));
-#ifdef TRGL_DEBUG_COUNTERS
-                zkill = cov && (zlow >= zold);
-                if (!dropped) {
-                    // what a test per 4x4-pixel cell could do at best: a lane survives if its plane value is below the largest
-                    // stored depth of ITS cell (the block-level masks compare the plane minimum with the block's maximum)
-                    double cm = zold;
-                    cm = dmax(cm, __shfl_xor(cm, 1)); cm = dmax(cm, __shfl_xor(cm, 2));
-                    cm = dmax(cm, __shfl_xor(cm, 8)); cm = dmax(cm, __shfl_xor(cm, 16));
-                    if (__ballot(cov) && !__ballot(cov && (zlow < cm))) TRGL_DBG(13, 1);
-                    if (__ballot(cov && !zkill) == 0 && __ballot(cov)) TRGL_DBG(14, 1);
-                }
 #else
-                cov = cov && !(zlow >= zold);
+            const bool alive = act && !(zpl >= zold);
 #endif
-            } else {
-                cov = false;
-                if (act) {
+            bool cov = false;
+            double ux = 0.0, uy = 0.0, us = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
+            if (alive) {
+                ux = T.s0y * s1z - s0z * T.s1y;                               // geometry.h:145
+                uy = s0z * T.s1x - T.s0x * s1z;                               // geometry.h:146
+                us = ux + uy;
+                if (WELL_SCALED) {
+                    // u.z < 0 and nothing can over/underflow, so the signs of the quotients are known
+                    // without dividing: u.y/u.z < 0 <=> u.y > 0, u.x/u.z < 0 <=> u.x > 0, and
+                    // 1 - RN(us/u.z) < 0 <=> RN(us/u.z) > 1 <=> us < u.z  ("exactness").
+                    cov = !(us < uz) && !(uy > 0.0) && !(ux > 0.0);               // :152
+                } else {
                     b0 = 1.0 - us / uz;                                           // :85, as written
                     b1 = uy / uz;
                     b2 = ux / uz;
@@ -407,7 +394,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                     TRGL_DBG(8, __popcll(__ballot(1)));                       // lanes that run the divisions
                     TRGL_DBG(9, __popcll(pass));                              // ... and write their pixel
                     if (!pass) TRGL_DBG(10, 1);                               // blocks that ran the divisions and wrote nothing
-                    if (!__ballot(!zkill)) TRGL_DBG(11, 1);                   // blocks the depth-plane test spares the divisions
+                    if (!__ballot(!zkill)) TRGL_DBG(11, 1);                   // blocks with covered pixels that the depth-plane test ends early
                     TRGL_DBG(12, __popcll(__ballot(zkill && __builtin_isfinite(z) && (z < zold))));   // lanes it would wrongly kill (must be 0)
                 }
 #endif
@@ -806,20 +793,25 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
             if (mine) {
                 uint4* d = tc + rank * CH;
                 d[0] = cur.q[0]; d[1] = cur.q[1]; d[2] = cur.q[2]; d[3] = cur.q[3]; d[4] = cur.q[4];
-                {   // depth plane of the per-pixel early test (raster_triangle): c0 + u.y g1 + u.x g2 < every covered pixel's z
+                {   // depth plane of the per-pixel early test (raster_triangle): c0 + (ax-x) g1 + (ay-y) g2 < every covered pixel's z
                     double c0 = -__builtin_inf(), g1 = 0.0, g2 = 0.0;
                     if (blocks_l & 0x10000u) {
+                        const double ax = __hiloint2double((int)cur.q[0].y, (int)cur.q[0].x), ay = __hiloint2double((int)cur.q[0].w, (int)cur.q[0].z);
+                        const double s0x = __hiloint2double((int)cur.q[1].y, (int)cur.q[1].x), s0y = __hiloint2double((int)cur.q[1].w, (int)cur.q[1].z);
+                        const double s1x = __hiloint2double((int)cur.q[2].y, (int)cur.q[2].x), s1y = __hiloint2double((int)cur.q[2].w, (int)cur.q[2].z);
+                        const double ruz = __hiloint2double((int)cur.q[3].w, (int)cur.q[3].z);
                         const double z0 = __hiloint2double((int)cur.q[4].y, (int)cur.q[4].x);
                         const double z1 = __hiloint2double((int)cur.q[4].w, (int)cur.q[4].z);
                         const double z2 = __hiloint2double((int)cur.q[5].y, (int)cur.q[5].x);
-                        const double ruz = __hiloint2double((int)cur.q[3].w, (int)cur.q[3].z);
                         const double zabs = dmax(dmax(fabs(z0), fabs(z1)), fabs(z2));
                         const double dz1 = z1 - z0, dz2 = z2 - z0;
-                        const double h1 = dz1 * ruz, h2 = dz2 * ruz;
-                        // trusted only while every constant is an ordinary number: |z| < 2^1000, slopes zero (exactly flat) or in [2^-900, 2^1000)
-                        const bool ok = zabs < 0x1p1000 && (dz1 == 0.0 || (fabs(h1) >= 0x1p-900 && fabs(h1) < 0x1p1000)) &&
-                                        (dz2 == 0.0 || (fabs(h2) >= 0x1p-900 && fabs(h2) < 0x1p1000));
-                        if (ok) { c0 = z0 - (zabs * 0x1p-40 + 0x1p-1000); g1 = h1; g2 = h2; }
+                        const double h1 = (s1x * dz1 - s1y * dz2) * ruz, h2 = (s0y * dz2 - s0x * dz1) * ruz;
+                        const double R = fabs(ax - ((double)px0 + 0.5)) + fabs(ay - ((double)py0 + 0.5)) + 64.0;   // >= |A - pixel| (L1) on the tile
+                        const double Ssum = (fabs(s0x) + fabs(s0y)) + (fabs(s1x) + fabs(s1y));
+                        const double mz = zabs * 0x1p-40 * (R * Ssum * fabs(ruz) + 1.0) + 0x1p-600;
+                        // trusted only while nothing can overflow (R |g| bounds each product of the test); NaN compares false
+                        const bool ok = zabs < 0x1p1000 && R * fabs(h1) < 0x1p900 && R * fabs(h2) < 0x1p900 && mz < 0x1p1000;
+                        if (ok) { c0 = z0 - mz; g1 = h1; g2 = h2; }
                     }
                     d[5] = make_uint4(cur.q[5].x, cur.q[5].y, (uint32_t)__double2loint(c0), (uint32_t)__double2hiint(c0));
                     d[6] = make_uint4((uint32_t)__double2loint(g1), (uint32_t)__double2hiint(g1), (uint32_t)__double2loint(g2), (uint32_t)__double2hiint(g2));
