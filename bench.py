@@ -358,12 +358,13 @@ def main():
         }
         # the two streaming phases next to the raster kernel, as bytes moved per second (HIP-event phase times):
         # k_setup reads 96 B of vertices + 4 B of colour and writes a 128-B record + 12 B per triangle; binning moves
-        # 52 B per pair (expand 8, two histogram reads 8, two scatter passes 32, bounds 4) + 12 B per triangle
+        # 36 B per pair with 16-bit tile keys (expand 6, two histogram reads 4, two scatter passes 24, bounds 2; 52 B with the 32-bit
+        # keys of frames beyond 65536 tiles) + 12 B per triangle
         setup_ms = phase_ms[PHASE_SETUP] / max(nfl, 1)
         bin_ms = phase_ms[PHASE_BIN] / max(nfl, 1)
         if kind == FLAT and setup_ms > 0 and bin_ms > 0:
             setup_bytes = N * (96 + 4 + 12) + (N / world) * 128
-            bin_bytes = info["pairs"] * 52 + N * 12
+            bin_bytes = info["pairs"] * (36 if ((W + 31) // 32) * ((H + 31) // 32) <= 65536 else 52) + N * 12
             out["streaming_phases"] = {
                 "k_setup": {"bytes": setup_bytes, "ms": setup_ms, "achieved": setup_bytes / (setup_ms * 1e-3) / 1e9,
                             "unit": "GB/s", "frac": setup_bytes / (setup_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},

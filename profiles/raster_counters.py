@@ -16,7 +16,8 @@ names = ["triangles scanned (slots read)", "blocks visited", "blocks with a cove
          "lanes of visited blocks inside the bbox", "list entries (pairs)", "visited blocks without a covered pixel",
          "blocks dropped by the per-lane masks", "... of which wrote a pixel (must be 0)",
          "covered lanes (before the depth-plane test)", "... that write their pixel", "blocks with covered pixels that write nothing",
-         "... of which the per-pixel depth-plane test ends before the coverage arithmetic", "lanes the depth-plane test would wrongly kill (must be 0)"
+         "... all of whose covered pixels the per-pixel depth-plane test kills (no divisions)", "lanes the depth-plane test would wrongly kill (must be 0)",
+         "visited blocks that end at the depth-plane test (no lane inside the bbox survives it)"
          ]
 for n, v in zip(names, out): print(f"{n:82s} {v:>12d}  per triangle {v / N:.3f}")
 # the diagnostic build counts what the depth-plane test WOULD skip and still runs it; the production kernel:

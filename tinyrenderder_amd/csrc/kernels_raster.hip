@@ -355,6 +355,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
             const bool zkill = act && (zpl >= zold);
             const bool alive = act;
             if (!dropped) TRGL_DBG(3, __popcll(__ballot(act)));                // lanes of visited blocks inside the bbox
+            if (!dropped && !__ballot(act && !zkill)) TRGL_DBG(13, 1);         // blocks the production kernel leaves at the depth-plane test
 #else
             const bool alive = act && !(zpl >= zold);
 #endif
