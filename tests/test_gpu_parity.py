@@ -389,6 +389,27 @@ def test_badly_scaled_triangles_take_the_literal_path():
     assert st == o.stats
 
 
+def test_literal_and_well_scaled_flushes_alternate_on_one_context():
+    """k_setup counts the triangles of a flush that are not well scaled; the host launches the raster kernel without the literal
+    path only when there are none.  A flush with such triangles, then one without, then one with again on the same context (the
+    count is per flush): every frame must equal the oracle's."""
+    W, H = 160, 128
+    n = 4000
+    clip, col = scenes.random_triangles(n, W, H, seed=515, rmin=2, rmax=30)
+    bad = clip.copy()
+    bad[::7, [0, 1, 4, 5, 8, 9]] *= 1e-260                    # edge deltas below 2^-250: not well scaled, still drawn by the reference's arithmetic
+    bad[3::11, 0] = 1e250                                      # a vertex beyond 2^200
+    with Context(W, H, 3) as ctx:
+        o = orc.Oracle(W, H, 3)
+        for k, batch in enumerate((bad, clip, bad, clip)):
+            part = batch[k * 1000:(k + 1) * 1000]; pc = col[k * 1000:(k + 1) * 1000]
+            ctx.draw(FLAT, part, colors=pc); ctx.flush()
+            o.draw(orc.FLAT, part, colors=pc)
+            assert np.array_equal(ctx.read_zbuffer().view(np.uint64), o.z.view(np.uint64)), k
+            assert np.array_equal(ctx.read_framebuffer(), o.fb), k
+        assert ctx.stats() == o.stats
+
+
 def test_bench_rccl_strip_gather_path_single_rank():
     """bench.py's N>1 code path (strip context + in-place RCCL all-gather on the context's own framebuffer memory,
     one stream shared with torch) rehearsed with a 1-rank process group: a 1-GPU box cannot host two RCCL ranks."""

@@ -181,6 +181,12 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
         __syncthreads();
         if (tid == 0) blk_sums[blk_base + blockIdx.x] = s_ws[0] + s_ws[1] + s_ws[2] + s_ws[3];
     }
+    // triangles with pairs that take the literal (dividing) path of k_raster: none in any realistic frame, and then the host
+    // launches the raster kernel that does not contain that path (trgl_flush_end)
+    {
+        const unsigned long long lit = __ballot(ntiles != 0 && r.ruz == 0.0);
+        if (lit && lane == 0) atomicAdd(&stats->literal_tris, (unsigned long long)__popcll(lit));
+    }
     // bbox stats (our_gl.cpp:138-141): one set of atomics per wave
     int wx0 = wave_min_i(bx0), wy0 = wave_min_i(by0), wx1 = wave_max_i(bx1), wy1 = wave_max_i(by1);
     // All waves hit the same four words, and same-address atomics serialise at ~11 ns each, so only

@@ -524,7 +524,9 @@ __device__ __forceinline__ void tile_clear_color(const FrameParams& fp, int lane
 }
 
 // BPP: the framebuffer's bytes per pixel when the kernel is compiled for one (3 or 4, FLAT only), 0 = read from FrameParams
-template <int KIND, int BPP = 0>
+// ALLWS: the flush holds no triangle that needs the literal path (k_setup counted them): the kernel is compiled without it, and the
+// block loop exists once (two loops sharing the wave's running statistics cost ten register moves per scanned triangle)
+template <int KIND, int BPP = 0, bool ALLWS = false>
 __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu((KIND == TRGL_SHADER_GOURAUD || KIND == 4) ? 3 : 4, 4))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ vals,
                                                 const uint32_t* __restrict__ tile_start,
@@ -848,7 +850,7 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
                 }
                 TRGL_DBG(0, 1);                                                    // list entries rasterized (not skipped)
                 // "well scaled" is a property of the triangle (k_setup leaves ruz = 0 otherwise): wave-uniform by construction
-                if (bw & 0x10000u) raster_triangle<KIND, true, BPP>(T, V, S, draws, tex, stats);
+                if (ALLWS || (bw & 0x10000u)) raster_triangle<KIND, true, BPP>(T, V, S, draws, tex, stats);
                 else raster_triangle<KIND, false, BPP>(T, V, S, draws, tex, stats);
             }
             __builtin_amdgcn_wave_barrier();
@@ -1081,6 +1083,7 @@ __global__ __launch_bounds__(1024) void k_fold_stats(DevStats* __restrict__ s, u
             s->zero_sign = s->zero_neg_key < s->zero_pos_key ? 1u : 0u;
             s->zero_locked = 1u;
         }
+        s->literal_tris = 0;                       // counted per flush (k_setup)
         s->zero_pos_key = TRGL_ZERO_KEY_EMPTY;
         s->zero_neg_key = TRGL_ZERO_KEY_EMPTY;
         *n_items = 0;           // every thread read it before the barrier; k_make_items of the next flush appends from 0
@@ -1112,7 +1115,7 @@ uint32_t raster_max_items(const FrameParams& fp, uint64_t pairs, uint32_t split_
     return (uint32_t)(tiles + extra);
 }
 
-void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER_* if uniform over the flush, else -1 */, const TriRec* recs, const uint32_t* vals,
+void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER_* if uniform over the flush, else -1 */, bool all_well_scaled, const TriRec* recs, const uint32_t* vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
                    const DevTexture* tex, DevStats* stats, uint32_t split_len, uint32_t max_items, uint32_t* items,
                    uint32_t* n_items, unsigned long long* item_stats, hipEvent_t ev_before, hipEvent_t ev_after) {
@@ -1128,13 +1131,19 @@ void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER
 #define TRGL_LAUNCH_RASTER(...) hipLaunchKernelGGL((k_raster<__VA_ARGS__>), grid, dim3(64 * TRGL_WAVES_PER_BLOCK), 0, s, fp, recs, vals, tile_start, tile_end, draws, tex, stats, items, n_items, item_stats)
     switch (kind) {
     case TRGL_SHADER_FLAT:
-        if (fp.bpp == 3) TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT, 3);
-        else if (fp.bpp == 4) TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT, 4);
-        else TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT);
+        if (all_well_scaled) {
+            if (fp.bpp == 3) TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT, 3, true);
+            else if (fp.bpp == 4) TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT, 4, true);
+            else TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT, 0, true);
+        } else {
+            if (fp.bpp == 3) TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT, 3);
+            else if (fp.bpp == 4) TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT, 4);
+            else TRGL_LAUNCH_RASTER(TRGL_SHADER_FLAT);
+        }
         break;
     case TRGL_SHADER_GOURAUD: TRGL_LAUNCH_RASTER(TRGL_SHADER_GOURAUD); break;
-    case TRGL_SHADER_PHONG:   TRGL_LAUNCH_RASTER(TRGL_SHADER_PHONG); break;
-    case TRGL_SHADER_EYE:     TRGL_LAUNCH_RASTER(TRGL_SHADER_EYE); break;
+    case TRGL_SHADER_PHONG:   if (all_well_scaled) TRGL_LAUNCH_RASTER(TRGL_SHADER_PHONG, 0, true); else TRGL_LAUNCH_RASTER(TRGL_SHADER_PHONG); break;
+    case TRGL_SHADER_EYE:     if (all_well_scaled) TRGL_LAUNCH_RASTER(TRGL_SHADER_EYE, 0, true); else TRGL_LAUNCH_RASTER(TRGL_SHADER_EYE); break;
     default:                  TRGL_LAUNCH_RASTER(KIND_ANY); break;
     }
 #undef TRGL_LAUNCH_RASTER

@@ -32,7 +32,7 @@ void launch_bounds(hipStream_t s, const void* keys, bool key16, const unsigned l
 
 uint32_t owned_tiles(const FrameParams& fp);       // tiles of the rows this context owns (strip or interleaved bands)
 uint32_t raster_max_items(const FrameParams& fp, uint64_t pairs, uint32_t split_len);
-void launch_raster(hipStream_t s, const FrameParams& fp, int kind, const TriRec* recs, const uint32_t* vals,
+void launch_raster(hipStream_t s, const FrameParams& fp, int kind, bool all_well_scaled, const TriRec* recs, const uint32_t* vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
                    const DevTexture* tex, DevStats* stats, uint32_t split_len, uint32_t max_items, uint32_t* items,
                    uint32_t* n_items, unsigned long long* item_stats, hipEvent_t ev_before = nullptr,

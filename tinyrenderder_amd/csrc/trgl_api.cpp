@@ -110,7 +110,7 @@ static int reset_dev_stats(trgl_ctx* c) {
     s.zmin_key = zkey_host(std::numeric_limits<double>::infinity());
     s.zmax_key = zkey_host(-std::numeric_limits<double>::infinity());
     s.min_x = INT32_MAX; s.min_y = INT32_MAX; s.max_x = INT32_MIN; s.max_y = INT32_MIN;
-    s.pairs_total = 0;
+    s.pairs_total = 0; s.literal_tris = 0;
     s.zero_pos_key = s.zero_neg_key = TRGL_ZERO_KEY_EMPTY;
     s.zero_locked = 0; s.zero_sign = 0;
     for (int k = 0; k < 16; ++k) s.dbg[k] = 0;
@@ -538,7 +538,7 @@ int trgl_flush_begin(trgl_ctx* c) {
         }
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
         launch_chunk_spine(s, c->blk_sums, nblk, c->chunk_off, &c->stats_dev->pairs_total);
-        HIPCHK(c, hipMemcpyAsync(&c->stats_pinned->pairs_total, &c->stats_dev->pairs_total, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&c->stats_pinned->pairs_total, &c->stats_dev->pairs_total, 16, hipMemcpyDeviceToHost, s));   // + literal_tris
         HIPCHK(c, hipEventRecord(c->ev_pairs, s));
         HIPCHK(c, hipMemsetAsync(c->tile_start, 0, ntiles * 8, s));                // tile_start and tile_end
         cap = (uint32_t)c->cap_pairs;
@@ -599,7 +599,9 @@ int trgl_flush_end(trgl_ctx* c) {
     const uint32_t max_items = raster_max_items(fp, P, split_len);
     if ((r = grow(c, c->items, c->cap_items, (size_t)max_items + 64))) return r;
     if ((r = grow(c, c->item_stats, c->cap_item_stats, ((size_t)max_items + 64) * 4))) return r;
-    launch_raster(s, fp, flush_kind, recs_arg, vals_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev,
+    // k_setup counted the triangles that are not well scaled (it came over with the pair count): without any, the kernel without the literal path
+    const bool all_well_scaled = N == 0 || c->stats_pinned->literal_tris == 0;
+    launch_raster(s, fp, flush_kind, all_well_scaled, recs_arg, vals_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev,
                   split_len, max_items, c->items, c->n_items, c->item_stats,
                   c->profiling ? c->ev[4] : nullptr, c->profiling ? c->ev[5] : nullptr);
     if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[3], s)); c->events_pending = true; }
