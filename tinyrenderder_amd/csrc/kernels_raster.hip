@@ -632,9 +632,12 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     // 64 records at a time: lane i holds the 128-B record of the batch's i-th triangle in registers for the batch phase
     // (block masks, one triangle per lane); the survivors' constants then go through LDS slots to all lanes.
     RecQ cur;
+    uint32_t next_tri = 0;               // list entry of this lane in the NEXT batch: fetched one batch ahead, so that the records
+                                         // of a batch are one memory latency away when its turn comes, not two
     if (beg < end) {                     // an empty tile must not touch vals/recs at all
         uint32_t p = beg + lane;
         cur = load_rec(recs, vals[p < end ? p : end - 1], true);
+        if (beg + 64 < end) { p += 64; next_tri = vals[p < end ? p : end - 1]; }
     } else {
         cur.tri = 0;
 #pragma unroll
@@ -856,8 +859,8 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
             __builtin_amdgcn_wave_barrier();
         }
         if (bs + 64 < end) {              // (holding the next batch's records during the scan costs a wave per SIMD; measured, not kept)
-            uint32_t p = bs + 64 + lane;
-            cur = load_rec(recs, vals[p < end ? p : end - 1], true);
+            cur = load_rec(recs, next_tri, true);
+            if (bs + 128 < end) { const uint32_t p = bs + 128 + lane; next_tri = vals[p < end ? p : end - 1]; }
         }
     }
 
