@@ -10,9 +10,9 @@ out = sys.argv[1]
 
 
 def short(name):
-    m = re.search(r"k_raster<(\d)(?:, (\d))?>", name)
+    m = re.search(r"k_raster<(\d)(?:, (\d))?(?:, (true|false))?>", name)
     if m:
-        return "k_raster<" + ["flat", "gouraud", "phong", "eye", "any"][int(m.group(1))] + (", bpp " + m.group(2) if m.group(2) and m.group(2) != "0" else "") + ">"
+        return "k_raster<" + ["flat", "gouraud", "phong", "eye", "any"][int(m.group(1))] + (", bpp " + m.group(2) if m.group(2) and m.group(2) != "0" else "") + (", all well scaled" if m.group(3) == "true" else "") + ">"
     m = re.search(r"k_shade<(\d)>", name)
     if m:
         return "k_shade<" + ["flat", "gouraud", "phong", "eye", "any"][int(m.group(1))] + ">"
