@@ -368,12 +368,14 @@ __global__ __launch_bounds__(256) void k_expand(FrameParams fp, uint32_t first, 
     K* const kdst = keys + base; uint32_t* const vdst = vals + base;
     constexpr uint32_t SMALL = 8;
     if (c && c <= SMALL) {
-        uint32_t tx0 = tb.x & 0xffff, ty0 = tb.x >> 16, tx1 = tb.y & 0xffff;
-        uint32_t wdt = tx1 - tx0 + 1;
+        // row-major walk with running counters instead of a division and a modulo per pair
+        const uint32_t tx0 = tb.x & 0xffff, ty0 = tb.x >> 16, tx1 = tb.y & 0xffff;
+        uint32_t tx = tx0, row = 0;
+        uint32_t ty = fp.il_tiles ? (uint32_t)il_nth_owned_from(fp, (int)ty0, 0) : ty0;
         for (uint32_t k = 0; k < c; ++k) {
-            uint32_t ty = fp.il_tiles ? (uint32_t)il_nth_owned_from(fp, (int)ty0, (int)(k / wdt)) : ty0 + k / wdt, tx = tx0 + k % wdt;
             const K key = (K)(ty * tiles_x + tx);
             if (staged) { s_k[o + k] = key; s_v[o + k] = i; } else { kdst[o + k] = key; vdst[o + k] = i; }
+            if (++tx > tx1) { tx = tx0; ++row; ty = fp.il_tiles ? (uint32_t)il_nth_owned_from(fp, (int)ty0, (int)row) : ty0 + row; }
         }
     }
     unsigned long long big = __ballot(c > SMALL);
