@@ -246,7 +246,7 @@ __device__ __forceinline__ double div_by_uz(double a, double uz, double ruz) {
 }
 
 // Per-triangle constants of the pixel loop.  Every lane holds the same values: they come from ONE broadcast read of the
-// triangle's slot in LDS (all lanes read the same address), which costs 7 LDS instructions and no vector-ALU issue slot;
+// triangle's slot in LDS (all lanes read the same address), which costs 8 LDS instructions and no vector-ALU issue slot;
 // the 31 v_readlane that used to move them into SGPRs were 22 % of the kernel's VALU instructions (profiles/r01_raster_pmc.txt).
 // Only the three words that steer control flow are made wave-uniform (v_readfirstlane).
 struct TriConst {
@@ -287,8 +287,8 @@ struct TileState {
 };
 
 // our_gl.cpp:147-199 for one triangle on one tile: 8x8 pixel blocks, one pixel per lane.
-// WELL_SCALED (see k_setup) selects the division-free coverage test and the FMA division by u.z; everything
-// after the coverage test sits under `if (cov)`, so a block with no covered pixel costs two scalar instructions.
+// WELL_SCALED (see k_setup) selects the division-free coverage test and the FMA division by u.z.  Three stages per block, each under
+// the lanes the one before left: per-pixel depth plane, coverage, divisions + exact z-test + stores.
 // KIND: the flush's shader kind when every draw has the same one (TRGL_SHADER_*), or KIND_ANY (per-triangle switch).
 // For GOURAUD / PHONG / EYE the triangle's varyings sit in lane j of the batch registers V (loaded with the records,
 // so the fragment branch never waits on memory) and are broadcast where a block actually shades.
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(64 * TRGL_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
             }
         }
         // ---- the surviving triangles, in list order (= ascending lane): constants to LDS, then one broadcast read each ----
-        // The survivors of the batch (57 % of its entries on C4) write their scan constants into consecutive 112-byte slots
+        // The survivors of the batch (57 % of its entries on C4) write their scan constants into consecutive 128-byte slots
         // of the wave's LDS area; a slot is read back by ALL lanes at the same address.  When there are more survivors than
         // slots the batch is served in rounds.
         constexpr int CH = FLAT_ONLY ? TC_CHUNKS_FLAT : TC_CHUNKS_ANY;
