@@ -491,6 +491,33 @@ def test_fuzz_flat_scenes_against_oracle(seed):
     assert st == o.stats
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_gouraud_scenes_against_oracle(seed):
+    """The GOURAUD kernel (three waves per SIMD, 10-chunk slots, perspective-correct barycentrics, colours from the varyings riding in
+    the batch registers) on dense overdraw with perspective w, extreme depths and two flushes: bits equal the oracle's."""
+    from tinyrenderder_amd.api import GOURAUD
+    rng = scenes.SplitMix64(9100 + seed)
+    u = rng.uniform(8)
+    W, H = int(96 + 200 * u[0]), int(96 + 160 * u[1])
+    n = int(4000 + 16000 * u[2])
+    bpp = (3, 4, 1, 3)[seed]
+    clip, col = scenes.random_triangles(n, W, H, seed=9200 + seed, rmin=2, rmax=20 + 60 * u[3], perspective_w=True)
+    clip = clip.copy()
+    inten = scenes.SplitMix64(9300 + seed).uniform(n * 3, -0.3, 1.4).reshape(n, 3)
+    clip[::5, [2, 6, 10]] *= 1.0 + 3.0 * u[4]                  # some depths beyond the clip range
+    clip[1::9, 6] = clip[1::9, 7] * 1e6                          # a far vertex: steep depth planes
+    half = n // 2
+    with Context(W, H, bpp) as ctx:
+        ctx.draw(GOURAUD, clip[:half], varyings=inten[:half], colors=col[:half]); ctx.flush()
+        ctx.draw(GOURAUD, clip[half:], varyings=inten[half:], colors=col[half:])
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    o = orc.Oracle(W, H, bpp)
+    o.draw(orc.GOURAUD, clip, inten, colors=col)
+    assert np.array_equal(z.view(np.uint64), o.z.view(np.uint64))
+    assert np.array_equal(fb, o.fb)
+    assert st == o.stats
+
+
 def test_mixed_flush_with_gouraud_runs_the_any_kernel():
     """One flush holding GOURAUD, PHONG, FLAT and EYE draws: k_raster<ANY> serves it, and its GOURAUD branch reads the
     varyings and base colours through the draw descriptor (d.vary + local * K), not from the batch registers."""
