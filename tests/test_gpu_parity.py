@@ -518,6 +518,51 @@ def test_fuzz_gouraud_scenes_against_oracle(seed):
     assert st == o.stats
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_phong_soup_against_oracle(seed):
+    """PHONG on a triangle soup with dense overdraw (the head stand-in is a closed surface: two layers at most): the deferred
+    path keeps, per pixel, the LAST triangle that passed the z-test, and k_shade recomputes its barycentrics.  Random varyings
+    (uv outside [0,1), unnormalised normals, degenerate tangent frames), perspective w, depth ties from duplicated triangles,
+    two flushes, strips on half of the seeds."""
+    from tinyrenderder_amd.api import PHONG, make_uniforms
+    rng = scenes.SplitMix64(9500 + seed)
+    u8 = rng.uniform(8)
+    W, H = int(96 + 160 * u8[0]), int(96 + 160 * u8[1])
+    n = int(3000 + 9000 * u8[2])
+    clip, _ = scenes.random_triangles(n, W, H, seed=9600 + seed, rmin=2, rmax=20 + 50 * u8[3], perspective_w=True)
+    clip = clip.copy()
+    vr = scenes.SplitMix64(9700 + seed)
+    uv = vr.uniform(n * 6, -0.5, 1.5).reshape(n, 6)
+    pos = vr.uniform(n * 9, -2.0, 2.0).reshape(n, 9)
+    nrm = vr.uniform(n * 9, -1.0, 1.0).reshape(n, 9)
+    nrm[::17] = 0.0                                             # zero normals: normalized() returns them unchanged
+    uv[::13, 2:4] = uv[::13, 0:2]                               # degenerate uv triangles: the tangent frame falls back
+    vary = np.ascontiguousarray(np.concatenate([uv, pos, nrm], 1))
+    k = n // 6
+    clip[k:2 * k] = clip[0:k]; vary[k:2 * k] = vary[0:k][::-1]  # same geometry, other attributes: the earlier triangle must win the tie
+    d, nm, sp = scenes.procedural_textures(64)
+    hd = scenes.head_standin(1, W, H)
+    uni = make_uniforms(hd["model_view"], hd["key"], hd["fill"], hd["rim"], 0.7, 0, 1, 2)
+    strip = None if seed % 2 else (H // 4, H - H // 3)
+    half = n // 2
+    with Context(W, H, 3) as ctx:
+        for slot, t in ((0, d), (1, nm), (2, sp)):
+            ctx.upload_texture(slot, t)
+        if strip:
+            ctx.set_strip(*strip)
+        ctx.draw(PHONG, clip[:half], varyings=vary[:half], uniforms=uni); ctx.flush()
+        ctx.draw(PHONG, clip[half:], varyings=vary[half:], uniforms=uni)
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    o = orc.Oracle(W, H, 3, strip=strip)
+    for slot, t in ((0, d), (1, nm), (2, sp)):
+        o.upload_texture(slot, t)
+    o.draw(orc.PHONG, clip, vary, uniforms=orc.Uniforms.from_buffer_copy(bytes(uni)))
+    rows = slice(None) if strip is None else slice(*strip)
+    assert np.array_equal(z[rows].view(np.uint64), o.z[rows].view(np.uint64))
+    assert np.array_equal(fb[rows], o.fb[rows])
+    assert st == o.stats
+
+
 def test_mixed_flush_with_gouraud_runs_the_any_kernel():
     """One flush holding GOURAUD, PHONG, FLAT and EYE draws: k_raster<ANY> serves it, and its GOURAUD branch reads the
     varyings and base colours through the draw descriptor (d.vary + local * K), not from the batch registers."""
