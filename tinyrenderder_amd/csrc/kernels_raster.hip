@@ -432,7 +432,7 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                         }
                     }
                     if (KIND >= TRGL_SHADER_PHONG && S.id_lane)               // a flush with PHONG / EYE draws (wave-uniform)
-                        S.id_lane[(size_t)(8 * cy) * S.row_px + (size_t)(8 * cx)] = shade_later ? T.tri : 0xffffffffu;
+                        S.id_lane[(size_t)(8 * cy) * S.row_px + (size_t)(8 * cx)] = shade_later ? T.dl : 0xffffffffu;   // draw << 24 | triangle in its draw (draw < 64)
 #ifdef TRGL_DEBUG_COUNTERS
                     if (dropped) TRGL_DBG(7, 1);                              // must stay 0
 #endif
@@ -919,31 +919,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int ya0 = max(py0 + band * band_rows, fp.strip_y0);
     const int ya1 = min(min(py0 + (band + 1) * band_rows - 1, fp.H - 1), fp.strip_y1 - 1);
     const int krow = 4 * (int)(threadIdx.x >> 6);
-    for (int k = krow; k < krow + 4; ++k) {
+    // The kernel is bound by dependent memory latencies (68 % of its wave time sat in s_waitcnt): owner -> record -> varyings -> texels
+    // for each of the wave's four blocks, sixteen in a row.  The four owners are fetched up front, and the visibility buffer holds
+    // `draw << 24 | triangle in its draw`, from which BOTH the record (recs[draw.first + triangle]) and the varyings are addressed:
+    // two loads in flight instead of one after the other.
+    uint32_t owner[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = krow + j;
         const int x = px0 + 8 * (k & 3) + (lane & 7), y = py0 + 8 * (k >> 2) + (lane >> 3);
         const bool mine = x <= xa1 && y >= ya0 && y <= ya1;
+        owner[j] = mine ? fp.idbuf[(size_t)x + (size_t)y * fp.W] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = krow + j;
+        const int x = px0 + 8 * (k & 3) + (lane & 7), y = py0 + 8 * (k >> 2) + (lane >> 3);
         const size_t idx = (size_t)x + (size_t)y * fp.W;
-        const uint32_t id = mine ? fp.idbuf[idx] : 0xffffffffu;
-        if (id == 0xffffffffu) continue;
-        const TriRec& r = recs[id];
-        // barycentric(), our_gl.cpp:77-86, as in raster_triangle
-        const double pxc = (double)x + 0.5, pyc = (double)y + 0.5;
-        const double s0z = r.ax - pxc, s1z = r.ay - pyc;
-        const double ux = r.s0y * s1z - s0z * r.s1y;
-        const double uy = s0z * r.s1x - r.s0x * s1z;
-        const double us = ux + uy;
-        double b0, b1, b2;
-        if (r.ruz != 0.0) {
-            b0 = 1.0 - div_by_uz(us, r.uz, r.ruz); b1 = div_by_uz(uy, r.uz, r.ruz); b2 = div_by_uz(ux, r.uz, r.ruz);
-        } else {
-            b0 = 1.0 - us / r.uz; b1 = uy / r.uz; b2 = ux / r.uz;
-        }
-        double pc[3];
-        const double denom = b0 * r.iw0 + b1 * r.iw1 + b2 * r.iw2;                        // our_gl.cpp:172-174
-        if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }                  // :177-185
-        else { pc[0] = (b0 * r.iw0) / denom; pc[1] = (b1 * r.iw1) / denom; pc[2] = (b2 * r.iw2) / denom; }
-        // the draw (uniforms, varyings array) is wave-uniform in all but exotic flushes: serve one draw at a time
-        const uint32_t dl = r.dl;
+        const uint32_t dl = owner[j];
+        if (dl == 0xffffffffu) continue;
+        // the draw (uniforms, varyings array, first record) is wave-uniform in all but exotic flushes: serve one draw at a time
         uint32_t color = 0;
         unsigned long long todo = __ballot(true);
         while (todo) {
@@ -953,7 +948,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             todo &= ~__ballot(here);
             if (here) {
                 const DrawDesc& d = draws[di];
-                const double* vary = d.vary + (size_t)(dl & 0xffffffu) * 24;
+                const uint32_t local = dl & 0xffffffu;
+                const TriRec& r = recs[d.first + local];
+                const double* vary = d.vary + (size_t)local * 24;
+                // barycentric(), our_gl.cpp:77-86, as in raster_triangle
+                const double pxc = (double)x + 0.5, pyc = (double)y + 0.5;
+                const double s0z = r.ax - pxc, s1z = r.ay - pyc;
+                const double ux = r.s0y * s1z - s0z * r.s1y;
+                const double uy = s0z * r.s1x - r.s0x * s1z;
+                const double us = ux + uy;
+                double b0, b1, b2;
+                if (r.ruz != 0.0) {
+                    b0 = 1.0 - div_by_uz(us, r.uz, r.ruz); b1 = div_by_uz(uy, r.uz, r.ruz); b2 = div_by_uz(ux, r.uz, r.ruz);
+                } else {
+                    b0 = 1.0 - us / r.uz; b1 = uy / r.uz; b2 = ux / r.uz;
+                }
+                double pc[3];
+                const double denom = b0 * r.iw0 + b1 * r.iw1 + b2 * r.iw2;                        // our_gl.cpp:172-174
+                if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }                  // :177-185
+                else { pc[0] = (b0 * r.iw0) / denom; pc[1] = (b1 * r.iw1) / denom; pc[2] = (b2 * r.iw2) / denom; }
                 const int kind = KIND == KIND_ANY ? d.kind : KIND;        // wave-uniform inside this iteration
                 color = kind == TRGL_SHADER_PHONG ? frag_phong(d.u, tex, vary, pc).bgra : frag_eye(d.u, tex, vary, pc).bgra;
             }

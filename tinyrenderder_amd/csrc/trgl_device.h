@@ -78,7 +78,7 @@ struct FrameParams;
 struct FrameParams {
     uint8_t* fb;
     double*  zb;
-    uint32_t* idbuf;                  // [H][W] record index of the triangle that owns the pixel (PHONG / EYE flushes), ~0u = none
+    uint32_t* idbuf;                  // [H][W] draw << 24 | index in the draw of the triangle that owns the pixel (PHONG / EYE flushes), ~0u = none
     int32_t  W, H, bpp;
     int32_t  tiles_x, tiles_y;
     int32_t  strip_y0, strip_y1;      // rows this context owns
