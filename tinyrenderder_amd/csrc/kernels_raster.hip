@@ -57,14 +57,17 @@ __device__ __forceinline__ unsigned long long zkey(double d) {       // order-pr
 // ---- samplers: model.cpp:415-459 + TGAImage::get tgaimage.cpp:24-30 ----------------------------
 struct Color { uint32_t bgra; int bytespp; };   // TGAColor (tgaimage.h:29-31), bgra[0] in the low byte
 
-__device__ __forceinline__ const DevTexture* tex_slot(const DevTexture* tex, int slot) {
+// (TX: pointer to DevTexture in the generic or in the constant address space - k_shade reads descriptors through scalar loads)
+template <class TX>
+__device__ __forceinline__ TX tex_slot(TX tex, int slot) {
     if (slot < 0 || slot >= TRGL_MAX_TEXTURES) return nullptr;
     if (!tex[slot].data || tex[slot].w <= 0) return nullptr;
     return &tex[slot];
 }
 // TGAImage::get at the clamped texel (model.cpp:420-425 etc.): ONE unaligned 4-byte load per texel (the device copy
 // of every texture is padded by 4 bytes), masked to bpp bytes = TGAColor(p, bpp) with the rest 0 (tgaimage.h:46-50).
-__device__ __forceinline__ uint32_t tex_fetch_raw(const DevTexture* t, const double* uv) {
+template <class TX>
+__device__ __forceinline__ uint32_t tex_fetch_raw(TX t, const double* uv) {
     int x = iclamp(x86_cvttsd2si(uv[0] * t->w), 0, t->w - 1);
     int y = iclamp(x86_cvttsd2si(uv[1] * t->h), 0, t->h - 1);
     const uint8_t* p = t->data + ((size_t)x + (size_t)y * t->w) * t->bpp;
@@ -72,8 +75,10 @@ __device__ __forceinline__ uint32_t tex_fetch_raw(const DevTexture* t, const dou
     __builtin_memcpy(&v, p, 4);
     return v;
 }
-__device__ __forceinline__ uint32_t tex_mask(const DevTexture* t) { return t->bpp >= 4 ? 0xffffffffu : ((1u << (8 * t->bpp)) - 1u); }
-__device__ __forceinline__ Color tex_fetch(const DevTexture* t, const double* uv) {
+template <class TX>
+__device__ __forceinline__ uint32_t tex_mask(TX t) { return t->bpp >= 4 ? 0xffffffffu : ((1u << (8 * t->bpp)) - 1u); }
+template <class TX>
+__device__ __forceinline__ Color tex_fetch(TX t, const double* uv) {
     return Color{ tex_fetch_raw(t, uv) & tex_mask(t), t->bpp };
 }
 __device__ __forceinline__ void interp(const double* v0, const double* v1, const double* v2, const double* b, int n, double* out) {
@@ -85,7 +90,8 @@ __device__ __forceinline__ double spec_pow(double x, double y) {
 }
 
 // PhongShader::fragment — main.cpp:92-170
-__device__ Color frag_phong(const trgl_uniforms& u, const DevTexture* tx, const double* vary, const double* b) {
+template <class UN, class TX>
+__device__ __forceinline__ Color frag_phong(const UN& u, TX tx, const double* vary, const double* b) {
     const double* uvv = vary; const double* pos = vary + 6; const double* nrm = vary + 15;
     double position_eye[3], geometry_normal[3], uv[2];
     interp(pos, pos + 3, pos + 6, b, 3, position_eye);
@@ -94,9 +100,9 @@ __device__ Color frag_phong(const trgl_uniforms& u, const DevTexture* tx, const 
 
     // the three maps are independent: issue all texel loads first, consume afterwards (the slots are per draw,
     // so these branches are wave-uniform)
-    const DevTexture* td = tex_slot(tx, u.tex_diffuse);
-    const DevTexture* ts = tex_slot(tx, u.tex_specular);
-    const DevTexture* tn = tex_slot(tx, u.tex_normal);
+    const TX td = tex_slot(tx, u.tex_diffuse);
+    const TX ts = tex_slot(tx, u.tex_specular);
+    const TX tn = tex_slot(tx, u.tex_normal);
     uint32_t raw_d = 0, raw_s = 0, raw_n = 0;
     if (td) raw_d = tex_fetch_raw(td, uv);
     if (ts) raw_s = tex_fetch_raw(ts, uv);
@@ -120,7 +126,7 @@ __device__ Color frag_phong(const trgl_uniforms& u, const DevTexture* tx, const 
     }
     double nme[3];                                                                            // main.cpp:116-119
     for (int r = 0; r < 3; ++r) {
-        const double* m = u.model_view + 4 * r;
+        const auto* m = u.model_view + 4 * r;
         double sum = 0; sum += m[0] * nmv[0]; sum += m[1] * nmv[1]; sum += m[2] * nmv[2]; sum += m[3] * 0.0;
         nme[r] = sum;
     }
@@ -135,15 +141,17 @@ __device__ Color frag_phong(const trgl_uniforms& u, const DevTexture* tx, const 
     for (int i = 0; i < 3; ++i) negp[i] = position_eye[i] * -1.0;
     normalized3(negp, V);
 
-    const double* Lk = u.key_light_dir_eye;
+    const double Lk[3] = { u.key_light_dir_eye[0], u.key_light_dir_eye[1], u.key_light_dir_eye[2] };
     double key_diffuse = dmax(0.0, dot3(N, Lk)) * 1.0;
     double k2 = 2.0 * dot3(N, Lk), rr[3], R[3];
     for (int i = 0; i < 3; ++i) rr[i] = N[i] * k2 - Lk[i];
     normalized3(rr, R);
     double rvd = dmax(0.0, dot3(R, V));
     double key_specular = (rvd > 0.0 ? spec_pow(rvd, specular_power) : 0.0) * 1.0;
-    double fill_diffuse = dmax(0.0, dot3(N, u.fill_light_dir_eye)) * 0.35;
-    double rim_diffuse = dmax(0.0, dot3(N, u.rim_light_dir_eye)) * 0.6;
+    const double Lf[3] = { u.fill_light_dir_eye[0], u.fill_light_dir_eye[1], u.fill_light_dir_eye[2] };
+    double fill_diffuse = dmax(0.0, dot3(N, Lf)) * 0.35;
+    const double Lr[3] = { u.rim_light_dir_eye[0], u.rim_light_dir_eye[1], u.rim_light_dir_eye[2] };
+    double rim_diffuse = dmax(0.0, dot3(N, Lr)) * 0.6;
     double total_diffuse = key_diffuse + fill_diffuse + rim_diffuse;
     double total_specular = key_specular;
     double ambient = 0.10;
@@ -158,7 +166,8 @@ __device__ Color frag_phong(const trgl_uniforms& u, const DevTexture* tx, const 
 }
 
 // EyeShader::fragment — main.cpp:220-261
-__device__ Color frag_eye(const trgl_uniforms& u, const DevTexture* tx, const double* vary, const double* b) {
+template <class UN, class TX>
+__device__ __forceinline__ Color frag_eye(const UN& u, TX tx, const double* vary, const double* b) {
     const double* uvv = vary; const double* pos = vary + 6; const double* nrm = vary + 15;
     double position_eye[3], ni[3], N[3], uv[2];
     interp(pos, pos + 3, pos + 6, b, 3, position_eye);
@@ -166,8 +175,8 @@ __device__ Color frag_eye(const trgl_uniforms& u, const DevTexture* tx, const do
     normalized3(ni, N);
     interp(uvv, uvv + 2, uvv + 4, b, 2, uv);
 
-    const DevTexture* td = tex_slot(tx, u.tex_diffuse);
-    const DevTexture* ts = tex_slot(tx, u.tex_specular);
+    const TX td = tex_slot(tx, u.tex_diffuse);
+    const TX ts = tex_slot(tx, u.tex_specular);
     uint32_t raw_d = 0, raw_s = 0;
     if (td) raw_d = tex_fetch_raw(td, uv);
     if (ts) raw_s = tex_fetch_raw(ts, uv);
@@ -176,9 +185,10 @@ __device__ Color frag_eye(const trgl_uniforms& u, const DevTexture* tx, const do
     for (int i = 0; i < 3; ++i) negp[i] = position_eye[i] * -1.0;
     normalized3(negp, V);
 
-    const double* Lk = u.key_light_dir_eye;
+    const double Lk[3] = { u.key_light_dir_eye[0], u.key_light_dir_eye[1], u.key_light_dir_eye[2] };
     double key_diffuse = dmax(0.0, dot3(N, Lk)) * 1.0;
-    double rim_diffuse = dmax(0.0, dot3(N, u.rim_light_dir_eye)) * 0.6;
+    const double Lr[3] = { u.rim_light_dir_eye[0], u.rim_light_dir_eye[1], u.rim_light_dir_eye[2] };
+    double rim_diffuse = dmax(0.0, dot3(N, Lr)) * 0.6;
     double total_diffuse = key_diffuse + rim_diffuse;
 
     float specf = ts ? (float)(int)(raw_s & 0xff) / 255.0f : 1.0f;
@@ -947,7 +957,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const bool here = (dl >> 24) == di;
             todo &= ~__ballot(here);
             if (here) {
-                const DrawDesc& d = draws[di];
+                // descriptors through the CONSTANT address space: the draw index is wave-uniform, so every field (uniforms, texture
+                // descriptors) comes in by scalar loads through the scalar cache.  As plain global loads they were vector loads, each
+                // waited for on its own: ~20 memory round trips in a row per block, 68 % of the kernel's wave time in s_waitcnt.
+                typedef const __attribute__((address_space(4))) DrawDesc CDraw;
+                typedef const __attribute__((address_space(4))) DevTexture CTex;
+                // (under `here` the compiler knows di == dl >> 24 and would address the draw per lane: re-derive it as a scalar)
+                const uint32_t di_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dl >> 24));
+                CDraw& d = ((CDraw*)draws)[di_s];
+                CTex* const ctex = (CTex*)tex;
                 const uint32_t local = dl & 0xffffffu;
                 const TriRec& r = recs[d.first + local];
                 const double* vary = d.vary + (size_t)local * 24;
@@ -968,7 +986,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 if (fabs(denom) < 1e-15) { pc[0] = b0; pc[1] = b1; pc[2] = b2; }                  // :177-185
                 else { pc[0] = (b0 * r.iw0) / denom; pc[1] = (b1 * r.iw1) / denom; pc[2] = (b2 * r.iw2) / denom; }
                 const int kind = KIND == KIND_ANY ? d.kind : KIND;        // wave-uniform inside this iteration
-                color = kind == TRGL_SHADER_PHONG ? frag_phong(d.u, tex, vary, pc).bgra : frag_eye(d.u, tex, vary, pc).bgra;
+                color = kind == TRGL_SHADER_PHONG ? frag_phong(d.u, ctex, vary, pc).bgra : frag_eye(d.u, ctex, vary, pc).bgra;
             }
         }
         uint8_t* dst = fp.fb + idx * fp.bpp;                                               // TGAImage::set, tgaimage.cpp:32-39
