@@ -500,7 +500,7 @@ def test_fuzz_gouraud_scenes_against_oracle(seed):
     u = rng.uniform(8)
     W, H = int(96 + 200 * u[0]), int(96 + 160 * u[1])
     n = int(4000 + 16000 * u[2])
-    bpp = (3, 4, 1, 3)[seed]
+    bpp = (3, 4, 1, 3)[seed % 4]
     clip, col = scenes.random_triangles(n, W, H, seed=9200 + seed, rmin=2, rmax=20 + 60 * u[3], perspective_w=True)
     clip = clip.copy()
     inten = scenes.SplitMix64(9300 + seed).uniform(n * 3, -0.3, 1.4).reshape(n, 3)
