@@ -1,0 +1,19 @@
+#!/bin/bash
+# SQ counters of k_raster on the c3 frame (PHONG head stand-in, 4096x4096): bash profiles/pmc_shade.sh <tag>
+set -e
+OUT=gpurun_out/pmc_c3raster_${1:-x}
+rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
+ARGS="bench.py --workload c3 --steps 3 --warmup 1 --cpu-sample 0 --writeout-frames 0 --no-parity --end-to-end-frames 0 --frames-in-flight 1"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_BRANCH --output-format csv -d $OUT/a -- python3 $ARGS > $OUT/a.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 --output-format csv -d $OUT/b -- python3 $ARGS > $OUT/b.log 2>&1
+python3 - <<PY
+import csv, glob
+from collections import defaultdict
+acc = defaultdict(list)
+for f in glob.glob("$OUT/*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_raster" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in sorted(acc.items()):
+    print(f"{k:28s} {sum(v)/len(v):.4g}  (n={len(v)})")
+PY

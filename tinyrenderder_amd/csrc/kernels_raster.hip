@@ -1076,6 +1076,10 @@ __global__ __launch_bounds__(256) void k_make_items(FrameParams fp, const uint32
     // wave-aggregated append (order of items is irrelevant)
     uint32_t inc = nb;
     const int lane = threadIdx.x & 63;
+    {   // tiles with triangles, for the host's band heuristic of the NEXT flush (n_items[1])
+        const unsigned long long ne = __ballot(nb != 0 && tile_end[t] != tile_start[t]);
+        if (ne && lane == 0) atomicAdd(n_items + 1, (uint32_t)__popcll(ne));
+    }
     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
     const uint32_t total = __shfl(inc, 63);
     uint32_t base = 0;
@@ -1121,6 +1125,7 @@ __global__ __launch_bounds__(1024) void k_fold_stats(DevStats* __restrict__ s, u
         s->zero_pos_key = TRGL_ZERO_KEY_EMPTY;
         s->zero_neg_key = TRGL_ZERO_KEY_EMPTY;
         *n_items = 0;           // every thread read it before the barrier; k_make_items of the next flush appends from 0
+        s->nonempty_tiles = n_items[1]; n_items[1] = 0;
     }
 }
 

@@ -110,7 +110,7 @@ static int reset_dev_stats(trgl_ctx* c) {
     s.zmin_key = zkey_host(std::numeric_limits<double>::infinity());
     s.zmax_key = zkey_host(-std::numeric_limits<double>::infinity());
     s.min_x = INT32_MAX; s.min_y = INT32_MAX; s.max_x = INT32_MIN; s.max_y = INT32_MIN;
-    s.pairs_total = 0; s.literal_tris = 0;
+    s.pairs_total = 0; s.literal_tris = 0; s.nonempty_tiles = 0;
     s.zero_pos_key = s.zero_neg_key = TRGL_ZERO_KEY_EMPTY;
     s.zero_locked = 0; s.zero_sign = 0;
     for (int k = 0; k < 16; ++k) s.dbg[k] = 0;
@@ -162,8 +162,8 @@ int trgl_create(int device, int width, int height, int bpp, trgl_ctx** out) {
     CRE(hipMemset(c->tex_dev, 0, sizeof(c->tex_host)));
     CRE(hipMalloc((void**)&c->tile_start, ntiles * 8));        // tile_start[ntiles] followed by tile_end[ntiles]: one memset per flush
     c->tile_end = c->tile_start + ntiles;
-    CRE(hipMalloc((void**)&c->n_items, 4));
-    CRE(hipMemset(c->n_items, 0, 4));                           // k_fold_stats leaves it at 0 for the next flush
+    CRE(hipMalloc((void**)&c->n_items, 8));                     // [0] work items of the flush, [1] its tiles with triangles
+    CRE(hipMemset(c->n_items, 0, 8));                           // k_fold_stats leaves it at 0 for the next flush
     CRE(hipMalloc((void**)&c->draws_dev, sizeof(DrawDesc) * TRGL_MAX_DRAWS));
     CRE(hipHostMalloc((void**)&c->draws_pinned, sizeof(DrawDesc) * TRGL_MAX_DRAWS));
     CRE(hipMalloc((void**)&c->stats_dev, sizeof(DevStats)));
@@ -538,7 +538,7 @@ int trgl_flush_begin(trgl_ctx* c) {
         }
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
         launch_chunk_spine(s, c->blk_sums, nblk, c->chunk_off, &c->stats_dev->pairs_total);
-        HIPCHK(c, hipMemcpyAsync(&c->stats_pinned->pairs_total, &c->stats_dev->pairs_total, 16, hipMemcpyDeviceToHost, s));   // + literal_tris
+        HIPCHK(c, hipMemcpyAsync(&c->stats_pinned->pairs_total, &c->stats_dev->pairs_total, 24, hipMemcpyDeviceToHost, s));   // + literal_tris, nonempty_tiles
         HIPCHK(c, hipEventRecord(c->ev_pairs, s));
         HIPCHK(c, hipMemsetAsync(c->tile_start, 0, ntiles * 8, s));                // tile_start and tile_end
         cap = (uint32_t)c->cap_pairs;
@@ -586,16 +586,24 @@ int trgl_flush_end(trgl_ctx* c) {
     // A lone wave needs ~1-3 us per list entry (one long dependent fp64 chain); throughput comes from many waves.
     // So lists longer than twice the mean list length (at least 8 entries) are cut into 2..16 row bands: dense
     // uniform scenes (C4: 1100 entries in every tile) never split, sparse or uneven ones (meshes) get parallelism.
-    const uint64_t strip_tiles = owned_tiles(fp);
+    uint64_t strip_tiles = owned_tiles(fp);
+    // "Mean" is over the tiles that HAVE triangles when the previous flush told us how many those were (a mesh covers a quarter of
+    // the screen: the mean over all tiles is four times too small and cut nearly every covered tile of the 4096^2 head frame into
+    // bands, each walking the same list).  The count came over with the pair count (DevStats::nonempty_tiles); 0 = not known yet.
+    if (N) {
+        const uint64_t hint = c->stats_pinned->nonempty_tiles;
+        if (hint && hint < strip_tiles) strip_tiles = hint;
+    }
     uint32_t split_len = 8;
     if (strip_tiles && 2 * (uint64_t)P / strip_tiles > split_len) split_len = (uint32_t)(2 * (uint64_t)P / strip_tiles);
-    // ... unless the strip has fewer tiles than the GPU has wave slots (a rank of a multi-GPU run, a small frame): then
+    // ... unless the strip has fewer (covered) tiles than the GPU has wave slots (a rank of a multi-GPU run, a small frame): then
     // bands are what fills the machine, and the target is about one item per slot (16 waves per CU).
     const uint64_t wave_slots = (uint64_t)c->num_cus * 16;
     if (strip_tiles && strip_tiles < wave_slots) {
         const uint64_t fill_len = 3 * (uint64_t)P / (2 * wave_slots);
         if (fill_len < split_len) split_len = (uint32_t)(fill_len > 8 ? fill_len : 8);
     }
+    if (const char* e = std::getenv("TRGL_SPLIT_LEN")) { const long v = std::atol(e); if (v > 0) split_len = (uint32_t)v; }   // experiments only
     const uint32_t max_items = raster_max_items(fp, P, split_len);
     if ((r = grow(c, c->items, c->cap_items, (size_t)max_items + 64))) return r;
     if ((r = grow(c, c->item_stats, c->cap_item_stats, ((size_t)max_items + 64) * 4))) return r;

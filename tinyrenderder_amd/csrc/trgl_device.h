@@ -60,6 +60,8 @@ struct DevStats {
     unsigned long long pairs_total;      // written by the scan spine (implementation traffic)
     unsigned long long literal_tris;     // triangles of the flush in flight that are not "well scaled" (k_setup adds, k_fold_stats clears); copied to the
                                          // host together with pairs_total: a flush without any runs the raster kernel that has no literal path
+    unsigned long long nonempty_tiles;   // tiles with triangles in the PREVIOUS flush (k_make_items counts, k_fold_stats publishes): rides with the
+                                         // two counts above and tells the host how long a tile's list has to be before it is cut into row bands
     // std::min/std::max keep the FIRST of two equal values (our_gl.cpp:197-198), and +0.0 == -0.0:
     // when the z range ends in a zero its sign is that of the first zero written, in the reference's
     // order (triangle, x, y).  Keys = tri<<32 | x<<16 | y of the first +0 / -0 fragment of this flush.
