@@ -14,7 +14,9 @@
 #define TRGL_TILE      32          // tile is TILE x TILE pixels, owned by ONE wavefront
 #define TRGL_TILE_LOG2 5
 #define TRGL_TILE_PIX  (TRGL_TILE * TRGL_TILE)
-#define TRGL_WAVES_PER_BLOCK 4     // a raster workgroup covers 4 horizontally adjacent tiles
+#ifndef TRGL_WAVES_PER_BLOCK
+#define TRGL_WAVES_PER_BLOCK 4     // a raster workgroup is 4 work items (2 and 8 waves per workgroup: 3 % slower on C4)
+#endif
 #define TRGL_MAX_DRAWS 64          // draws per flush (each with its own shader kind + uniforms)
 
 // Per-triangle setup record: everything the pixel loop needs, hoisted exactly as SURVEY §8(a) A4/A6
