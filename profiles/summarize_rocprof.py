@@ -16,7 +16,7 @@ def short(name):
     m = re.search(r"k_shade<(\d)>", name)
     if m:
         return "k_shade<" + ["flat", "gouraud", "phong", "eye", "any"][int(m.group(1))] + ">"
-    for k in ("k_setup", "k_chunk_spine", "k_scan_reduce", "k_scan_spine", "k_scan_apply", "k_expand", "k_radix_hist", "k_radix_scatter",
+    for k in ("k_setup", "k_chunk_spine", "k_radix_scan_rows", "k_expand", "k_radix_hist", "k_radix_scatter",
               "k_bounds", "k_make_items", "k_fold_stats", "k_selftest_division"):
         if k in name:
             return k

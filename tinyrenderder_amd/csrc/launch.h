@@ -11,9 +11,6 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc* draws_de
 // chunk_off[c] = pairs before setup block 16c; *total64 = all pairs of the flush
 void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, uint32_t* chunk_off, unsigned long long* total64);
 
-uint32_t scan_num_blocks(uint64_t n);
-void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* block_sums,
-                           unsigned long long* total64);
 
 // expand / radix / bounds read the flush's pair count from device memory and cover `cap` (the capacity of the pair buffers)
 // with their grids; they do nothing when the count exceeds it (the host then grows the buffers and queues them again)

@@ -448,7 +448,7 @@ static int queue_binning(trgl_ctx* c, const FrameParams& fp, uint32_t cap, int* 
     int bits_per = (key_bits + passes - 1) / passes;
     size_t hist_need = ((size_t)radix_num_workers(cap) << bits_per) + 16;
     if ((r = grow(c, c->hist, c->cap_hist, hist_need))) return r;
-    if ((r = grow(c, c->scan_tmp, c->cap_scan, (size_t)scan_num_blocks(hist_need) + 16))) return r;
+    if ((r = grow(c, c->scan_tmp, c->cap_scan, 256 + 16))) return r;   // the digit totals of a pass (k_radix_scan_rows)
     int cur = 0;
     for (int ps = 0; ps < passes; ++ps) {
         launch_radix_pass(s, c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1], key16, pairs_dev, cap, ps * bits_per, bits_per,
