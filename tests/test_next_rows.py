@@ -196,3 +196,62 @@ def test_obj_to_screen_through_device_vertex_stage(tmp_path):
     o.draw(orc.PHONG, clip, vary, uniforms=orc.make_uniforms(hd["model_view"], hd["key"], hd["fill"], hd["rim"], 1.0, 0, 1, 2))
     assert np.array_equal(z.view(np.uint64), o.z.view(np.uint64)) and np.array_equal(fb, o.fb) and st == o.stats
     assert st[1] > 10_000
+
+
+def _c_round(v):
+    """C round(): half away from zero, exactly (np.rint is half-to-even; floor(v + 0.5) is wrong just below a half)."""
+    r = np.trunc(v)
+    return np.where(np.abs(v - r) >= 0.5, r + np.sign(v), r)
+
+
+def _numpy_ssao(z, ndir, steps, radius, threshold, intensity):
+    """main.cpp:317-362,757-763 for arbitrary parameters, vectorised over the pixels (fp64, the reference's operation order)."""
+    import math
+    h, w = z.shape
+    ys, xs = np.mgrid[0:h, 0:w]
+    occluded = np.zeros((h, w), np.int64); total = np.zeros((h, w), np.int64)
+    live = np.isfinite(z)
+    for d in range(ndir):
+        angle = 2.0 * 3.14159265358979323846 * d / ndir
+        dx, dy = math.cos(angle), math.sin(angle)
+        for step in range(1, steps + 1):
+            r = float(step) / steps * radius
+            sx = _c_round(xs + dx * r).astype(np.int64); sy = _c_round(ys + dy * r).astype(np.int64)
+            inside = (sx >= 0) & (sx < w) & (sy >= 0) & (sy < h) & live
+            sd = z[np.clip(sy, 0, h - 1), np.clip(sx, 0, w - 1)]
+            fin = np.isfinite(sd)
+            with np.errstate(invalid="ignore"):
+                occ = inside & fin & (sd < z - threshold)
+            total += inside; occluded += occ
+    ao = np.ones((h, w))
+    m = live & (total != 0)
+    ao[m] = 1.0 - (occluded[m].astype(np.float64) / total[m].astype(np.float64)) * intensity
+    val = (255.0 * ao).astype(np.uint8)
+    return np.repeat(val[..., None], 3, -1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("params", [(8, 8, 16.0, 1e-3, 0.35), (5, 3, 7.5, 0.02, 0.8), (16, 20, 12.0, 1e-3, 0.5), (7, 6, 40.0, 1e-3, 0.35),
+                                    (3, 1, 0.4, 0.0, 1.0)])
+def test_gpu_ssao_paths_against_numpy(params):
+    """k_ssao takes integer sample offsets when they are exact for a block, counts interior blocks without range tests, leaves
+    background blocks early, reads the z-buffer directly for radii beyond its 16-pixel halo and falls back to the literal
+    arithmetic for more than 256 samples: every path against a plain numpy evaluation, on a z-buffer with NaN, -inf, +inf,
+    an empty region (background blocks), image edges that cut blocks (150 x 97) and exact ties at the threshold."""
+    from tinyrenderder_amd.api import Context, SsaoParams
+    ndir, steps, radius, thr, inten = params
+    W, H = 150, 97
+    rng = scenes.SplitMix64(4100 + ndir * 31 + steps)
+    z = rng.uniform(W * H, -1.0, 1.0).reshape(H, W)
+    z = np.round(z * 64) / 64                                   # few distinct depths: differences exactly at the threshold occur
+    z[:, 100:] = np.inf                                         # background (whole blocks without a finite depth)
+    z[10:14, 20:40] = np.nan; z[30:33, 5:60] = -np.inf; z[50:70:3, 0:90:4] = np.inf
+    sp = SsaoParams(ndir, steps, radius, thr, inten)
+    with Context(W, H, 3) as ctx:
+        ctx.write_zbuffer(z)
+        got = ctx.postprocess(zbuffer_image=False, ao=True, final=False, params=sp)["ao"]
+    want = _numpy_ssao(z, ndir, steps, radius, thr, inten)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, f"{len(bad)} differing bytes, first at {bad[:5].tolist()}"
+    if params == (8, 8, 16.0, 1e-3, 0.35):
+        assert np.array_equal(got, orc.ssao(z))                 # the reference's own parameters: the C restatement agrees too
