@@ -419,7 +419,9 @@ __device__ __forceinline__ void raster_triangle(const TriConst& T, const VaryQ& 
                     if (FLAT_ONLY) {
                         color = T.color;
                     } else if (KIND == TRGL_SHADER_GOURAUD || KIND == KIND_ANY) {
-                        const DrawDesc& d = draws[T.dl >> 24];
+                        // (constant address space + wave-uniform index: the descriptor's fields come by scalar loads, see k_shade)
+                        typedef const __attribute__((address_space(4))) DrawDesc CDraw;
+                        CDraw& d = ((CDraw*)draws)[T.dl >> 24];
                         const int kind = KIND == KIND_ANY ? d.kind : KIND;
                         if (kind == TRGL_SHADER_FLAT) {
                             color = T.color;
