@@ -53,23 +53,30 @@ extern "C" {
  * Varyings layout for PHONG/EYE is the memory image of the shader's three member arrays
  * (main.cpp:47-49,181-183): uv[3] (6 doubles), position_eye[3] (9), normal_eye[3] (9).
  *
- * Contract: no device kind ever discards.  rasterize() skips the depth and colour write when fragment() returns
- * {true, ...} (our_gl.cpp:187-188); both shaders the reference ships always return false (main.cpp:169,260), and so do the
- * four kinds above.  The PHONG/EYE path relies on it: with no discard and no side effects in fragment(), shading only the
- * last fragment that passed the z-test at a pixel gives the framebuffer of shading every z-pass in order.  A shader that
- * discards needs its own kind with in-order shading; it cannot be expressed through this interface today.
+ *   CHECKER : the kind that DISCARDS (our_gl.h:51, our_gl.cpp:187-188: `if (discard) continue;` skips the depth write, the
+ *             colour write and the counters).  One BGRA colour per triangle as for FLAT; fragment(bar) returns
+ *             { (((int)(bar[0] * cells) ^ (int)(bar[1] * cells)) & 1) != 0, colour } with cells = uniforms->reserved and bar the
+ *             perspective-correct barycentrics rasterize() passes (our_gl.cpp:168-185).  Its fragments are evaluated in
+ *             submission order per pixel, like FLAT and GOURAUD ones.  (The reference ships no discarding shader; this is the
+ *             plugin surface's discard path made testable: oracle/ref_harness.cpp holds the same IShader subclass.)
+ *
+ * PHONG / EYE are shaded once per visible pixel: with no discard and no side effects in fragment() (main.cpp:92-170,220-261
+ * always return false), shading only the last fragment that passed the z-test at a pixel gives the framebuffer of shading
+ * every z-pass in order.  A new kind whose fragment() can discard must be shaded in order, as CHECKER is.
  */
 #define TRGL_SHADER_FLAT    0
 #define TRGL_SHADER_GOURAUD 1
 #define TRGL_SHADER_PHONG   2
 #define TRGL_SHADER_EYE     3
-#define TRGL_NUM_SHADERS    4
+#define TRGL_SHADER_CHECKER 4
+#define TRGL_NUM_SHADERS    5
 
 /* doubles of varyings per triangle for each kind */
 #define TRGL_VARY_FLAT    0
 #define TRGL_VARY_GOURAUD 3
 #define TRGL_VARY_PHONG   24
 #define TRGL_VARY_EYE     24
+#define TRGL_VARY_CHECKER 0
 
 /*
  * Uniform block for PHONG / EYE (ignored by FLAT / GOURAUD; may be NULL for those).
@@ -88,7 +95,7 @@ typedef struct trgl_uniforms {
     int32_t tex_diffuse;
     int32_t tex_normal;               /* PHONG only */
     int32_t tex_specular;
-    int32_t reserved;
+    int32_t reserved;                 /* CHECKER: cells per barycentric axis (>= 1) */
 } trgl_uniforms;
 
 /* The reference's diagnostic counters (our_gl.cpp:18-22), per context instead of process-global. */

@@ -46,7 +46,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 constexpr int SETUP_THREADS = 256;
 
 __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const DrawDesc* __restrict__ draws, int draw_idx,
-                                                         TriRec* __restrict__ recs, uint32_t* __restrict__ cnt,
+                                                         TriRec* __restrict__ recs, TriW* __restrict__ recs_w, uint32_t* __restrict__ cnt,
                                                          uint2* __restrict__ tilebox, DevStats* __restrict__ stats,
                                                          uint32_t* __restrict__ blk_sums, uint32_t blk_base) {
     __shared__ __attribute__((aligned(16))) double s_buf[SETUP_THREADS * 16];    // 32 KB: in [256][12], then out [256][16]
@@ -128,12 +128,40 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
                 r.ruz = ws ? 1.0 / r.uz : 0.0;
             }
             r.z0 = ndc[2]; r.z1 = ndc[6]; r.z2 = ndc[10];
-            r.iw0 = (fabs(v[3]) > 1e-12) ? (1.0 / v[3]) : 0.0;                             // :168-170
-            r.iw1 = (fabs(v[7]) > 1e-12) ? (1.0 / v[7]) : 0.0;
-            r.iw2 = (fabs(v[11]) > 1e-12) ? (1.0 / v[11]) : 0.0;
             r.bx0 = (uint16_t)bx0; r.by0 = (uint16_t)by0; r.bx1 = (uint16_t)bx1; r.by1 = (uint16_t)by1;
             r.color = d.colors ? d.colors[i] : 0xffffffffu;
-            r.dl = ((uint32_t)draw_idx << 24) | i;
+            r.dl = ((uint32_t)draw_idx << 24) | i | (r.ruz == 0.0 ? TRGL_DL_LITERAL : 0u);
+            // Depth plane of the early depth test (k_raster).  The z of our_gl.cpp:156-158 is the plane
+            //   z0 + ((ax - x) Gx + (ay - y) Gy) / u.z,  Gx = s1x (z1-z0) - s1y (z2-z0),  Gy = s0y (z2-z0) - s0x (z1-z0)
+            // through the three vertices up to the roundings of u.x, u.y, the three quotients and the weighted sum: at most
+            // 2^-50 max|z_i| (R S / |u.z| + 1) for a covered pixel, where R >= |A - pixel centre| (L1) over the clamped bbox and
+            // S = the sum of the |edge deltas|.  g1 = Gx/u.z and g2 = Gy/u.z carry a few more roundings of that size, so does the
+            // evaluation c0 + (ax - x) g1 + (ay - y) g2 itself, and c0 = z0 - 2^-39 max|z_i| (R S / |u.z| + 1) covers all of it a
+            // thousand times over: a pixel whose plane value is >= the stored depth fails the strict `<` of :165 whatever its
+            // coverage and low bits.  Switched off (c0 = -inf, g = 0) for triangles that are not well scaled and when a constant
+            // could leave the normal range.
+            r.c0 = -__builtin_inf(); r.g1 = 0.0; r.g2 = 0.0;
+            if (r.ruz != 0.0) {
+                const double zabs = dmax3(fabs(r.z0), fabs(r.z1), fabs(r.z2));
+                const double dz1 = r.z1 - r.z0, dz2 = r.z2 - r.z0;
+                const double h1 = (r.s1x * dz1 - r.s1y * dz2) * r.ruz, h2 = (r.s0y * dz2 - r.s0x * dz1) * r.ruz;
+                const double rx = fmax(fabs(r.ax - ((double)bx0 + 0.5)), fabs(r.ax - ((double)bx1 + 0.5)));
+                const double ry = fmax(fabs(r.ay - ((double)by0 + 0.5)), fabs(r.ay - ((double)by1 + 0.5)));
+                const double R = rx + ry + 1.0;
+                const double Ssum = (fabs(r.s0x) + fabs(r.s0y)) + (fabs(r.s1x) + fabs(r.s1y));
+                const double mz = zabs * 0x1p-39 * (R * Ssum * fabs(r.ruz) + 1.0) + 0x1p-600;
+                // trusted only while nothing can overflow (R |g| bounds each product of the test); NaN compares false
+                const bool okp = zabs < 0x1p1000 && R * fabs(h1) < 0x1p900 && R * fabs(h2) < 0x1p900 && mz < 0x1p1000;
+                if (okp) { r.c0 = r.z0 - mz; r.g1 = h1; r.g2 = h2; }
+            }
+            if (d.kind != TRGL_SHADER_FLAT) {                                                  // :168-170
+                TriW w;
+                w.iw0 = (fabs(v[3]) > 1e-12) ? (1.0 / v[3]) : 0.0;
+                w.iw1 = (fabs(v[7]) > 1e-12) ? (1.0 / v[7]) : 0.0;
+                w.iw2 = (fabs(v[11]) > 1e-12) ? (1.0 / v[11]) : 0.0;
+                w.pad = 0.0;
+                recs_w[d.first + i] = w;
+            }
             // barycentric() rejects every pixel when |u.z| < 1e-12 (our_gl.cpp:82-83): no pairs then.
             // Rows outside this context's strip are not ours either.
             int y_lo = max(by0, fp.strip_y0), y_hi = min(by1, fp.strip_y1 - 1);
@@ -144,7 +172,10 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
                 // its bands with interleaved ownership (k_expand walks the same rows)
                 const uint32_t rows = fp.il_tiles ? (uint32_t)(il_owned_below(fp, (int)ty1 + 1) - il_owned_below(fp, (int)ty0)) : ty1 - ty0 + 1;
                 ntiles = (tx1 - tx0 + 1) * rows;
-                tb = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
+                // the box in BLOCK units (8 x 8 pixels; tile = block >> 2): k_expand derives from it, for every tile of the box,
+                // the 4 x 4 mask of the tile's blocks that the box reaches
+                tb = make_uint2(((uint32_t)bx0 >> TRGL_BLOCK_LOG2) | (((uint32_t)y_lo >> TRGL_BLOCK_LOG2) << 16),
+                                ((uint32_t)bx1 >> TRGL_BLOCK_LOG2) | (((uint32_t)y_hi >> TRGL_BLOCK_LOG2) << 16));
             }
         }
         cnt[d.first + i] = ntiles;
@@ -277,17 +308,26 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_chunk_spine(const uint32_t* _
 // The pairs of a block are consecutive in the output (the offsets are a prefix sum in submission order), so they are
 // assembled in LDS and written out linearly: whole cache lines instead of 64 lanes x a few elements each with a stride.
 // A block whose triangles cover more than EXPAND_STAGE tiles writes straight to memory.
+// Every pair also carries the 4 x 4 mask of the tile's 8 x 8-pixel blocks that the triangle's clamped bbox reaches (bit 4 cy + cx):
+// the raster wave that owns a block picks its candidates from the tile's list by that bit, without touching their records.
 // K: the key type, 16 bits while the frame has at most 65536 tiles (up to 8192x8192), 32 bits beyond.
 constexpr uint32_t EXPAND_STAGE = 3072;
+// blocks of tile (tx, ty) inside the block-unit box [qx0, qx1] x [qy0, qy1] (the box reaches the tile)
+__device__ __forceinline__ uint32_t tile_block_mask(uint32_t tx, uint32_t ty, uint32_t qx0, uint32_t qy0, uint32_t qx1, uint32_t qy1) {
+    const uint32_t c0 = qx0 > 4 * tx ? qx0 - 4 * tx : 0u, c1 = qx1 < 4 * tx + 3 ? qx1 - 4 * tx : 3u;
+    const uint32_t r0 = qy0 > 4 * ty ? qy0 - 4 * ty : 0u, r1 = qy1 < 4 * ty + 3 ? qy1 - 4 * ty : 3u;
+    return (((2u << c1) - (1u << c0)) & 0xfu) * 0x1111u & ((0xffffu >> (12 - 4 * r1)) & (0xffffu << (4 * r0)));
+}
 template <typename K>
 __global__ __launch_bounds__(256) void k_expand(FrameParams fp, uint32_t first, uint32_t n, int tiles_x, const uint32_t* __restrict__ cnt,
                                                 const uint32_t* __restrict__ blk_sums, const uint32_t* __restrict__ chunk_off,
                                                 uint32_t blk_base, const uint2* __restrict__ tilebox,
-                                                K* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                K* __restrict__ keys, uint32_t* __restrict__ vals, uint16_t* __restrict__ bmask,
                                                 const unsigned long long* __restrict__ pairs_total, uint32_t cap) {
     __shared__ uint32_t smem[4];
     __shared__ uint32_t s_v[EXPAND_STAGE];
     __shared__ K s_k[EXPAND_STAGE];
+    __shared__ uint16_t s_m[EXPAND_STAGE];
     if (*pairs_total > cap) return;        // the host sized the buffers from an earlier flush: it will grow them and launch again
     const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = first + local;                          // index of the triangle within the flush
@@ -299,16 +339,18 @@ __global__ __launch_bounds__(256) void k_expand(FrameParams fp, uint32_t first, 
     uint32_t tot;
     const uint32_t o = block_excl_scan(c, smem, &tot);         // offset inside the block's run of pairs
     const bool staged = tot <= EXPAND_STAGE;                   // block-uniform
-    K* const kdst = keys + base; uint32_t* const vdst = vals + base;
+    K* const kdst = keys + base; uint32_t* const vdst = vals + base; uint16_t* const mdst = bmask + base;
     constexpr uint32_t SMALL = 8;
     if (c && c <= SMALL) {
         // row-major walk with running counters instead of a division and a modulo per pair
-        const uint32_t tx0 = tb.x & 0xffff, ty0 = tb.x >> 16, tx1 = tb.y & 0xffff;
+        const uint32_t qx0 = tb.x & 0xffff, qy0 = tb.x >> 16, qx1 = tb.y & 0xffff, qy1 = tb.y >> 16;
+        const uint32_t tx0 = qx0 >> 2, ty0 = qy0 >> 2, tx1 = qx1 >> 2;
         uint32_t tx = tx0, row = 0;
         uint32_t ty = fp.il_tiles ? (uint32_t)il_nth_owned_from(fp, (int)ty0, 0) : ty0;
         for (uint32_t k = 0; k < c; ++k) {
             const K key = (K)(ty * tiles_x + tx);
-            if (staged) { s_k[o + k] = key; s_v[o + k] = i; } else { kdst[o + k] = key; vdst[o + k] = i; }
+            const uint16_t m = (uint16_t)tile_block_mask(tx, ty, qx0, qy0, qx1, qy1);
+            if (staged) { s_k[o + k] = key; s_v[o + k] = i; s_m[o + k] = m; } else { kdst[o + k] = key; vdst[o + k] = i; mdst[o + k] = m; }
             if (++tx > tx1) { tx = tx0; ++row; ty = fp.il_tiles ? (uint32_t)il_nth_owned_from(fp, (int)ty0, (int)row) : ty0 + row; }
         }
     }
@@ -319,17 +361,19 @@ __global__ __launch_bounds__(256) void k_expand(FrameParams fp, uint32_t first, 
         big &= big - 1;
         uint32_t cc = __shfl(c, src), oo = __shfl(o, src), ii = __shfl(i, src);
         uint32_t bx = __shfl(tb.x, src), by = __shfl(tb.y, src);
-        uint32_t tx0 = bx & 0xffff, ty0 = bx >> 16, tx1 = by & 0xffff;
+        const uint32_t qx0 = bx & 0xffff, qy0 = bx >> 16, qx1 = by & 0xffff, qy1 = by >> 16;
+        uint32_t tx0 = qx0 >> 2, ty0 = qy0 >> 2, tx1 = qx1 >> 2;
         uint32_t wdt = tx1 - tx0 + 1;
         for (uint32_t k = lane; k < cc; k += 64) {
             uint32_t ty = fp.il_tiles ? (uint32_t)il_nth_owned_from(fp, (int)ty0, (int)(k / wdt)) : ty0 + k / wdt, tx = tx0 + k % wdt;
             const K key = (K)(ty * tiles_x + tx);
-            if (staged) { s_k[oo + k] = key; s_v[oo + k] = ii; } else { kdst[oo + k] = key; vdst[oo + k] = ii; }
+            const uint16_t m = (uint16_t)tile_block_mask(tx, ty, qx0, qy0, qx1, qy1);
+            if (staged) { s_k[oo + k] = key; s_v[oo + k] = ii; s_m[oo + k] = m; } else { kdst[oo + k] = key; vdst[oo + k] = ii; mdst[oo + k] = m; }
         }
     }
     if (staged) {
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < tot; j += 256) { kdst[j] = s_k[j]; vdst[j] = s_v[j]; }
+        for (uint32_t j = threadIdx.x; j < tot; j += 256) { kdst[j] = s_k[j]; vdst[j] = s_v[j]; mdst[j] = s_m[j]; }
     }
 }
 
@@ -411,15 +455,17 @@ __global__ __launch_bounds__(ROWSCAN_THREADS) void k_radix_scan_rows(uint32_t* _
 
 template <typename K>
 __global__ __launch_bounds__(256) void k_radix_scatter(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                       const uint16_t* __restrict__ msk_in,
                                                        const unsigned long long* __restrict__ pairs_total, uint32_t cap,
                                                        int shift, int bits, uint32_t nblocks,
                                                        const uint32_t* __restrict__ base, const uint32_t* __restrict__ totals,
-                                                       K* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+                                                       K* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint16_t* __restrict__ msk_out) {
     __shared__ uint32_t s_cnt[4][1 << RADIX_MAX_BITS];     // per wave: running count, then (after phase 2) local start
     __shared__ uint32_t s_start[1 << RADIX_MAX_BITS];      // first local position of each digit in the chunk
     __shared__ uint32_t s_gbase[1 << RADIX_MAX_BITS];      // global position of the chunk's first pair of each digit
     __shared__ uint32_t s_val[RADIX_CHUNK];
     __shared__ K s_key[RADIX_CHUNK];
+    __shared__ uint16_t s_msk[RADIX_CHUNK];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned long long P64 = *pairs_total;
     const uint32_t P = P64 > cap ? 0u : (uint32_t)P64;
@@ -449,12 +495,14 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const K* __restrict__ key
     const unsigned long long lt = (1ull << lane) - 1ull;
 
     // ---- phase 1: stable rank of every pair among the equal digits of its wave's quarter ------------
+    // (key and block mask share a register: key in the low 16 bits when K is 16 bits wide; else the mask rides in its own)
     uint32_t k[RADIX_ROUNDS], v[RADIX_ROUNDS], rk[RADIX_ROUNDS];
+    uint16_t mk[RADIX_ROUNDS];
 #pragma unroll
     for (int r = 0; r < RADIX_ROUNDS; ++r) {
         const uint64_t p = wbeg + (uint64_t)r * 64 + lane;
         const bool act = p < cend;
-        k[r] = act ? (uint32_t)keys_in[p] : 0; v[r] = act ? vals_in[p] : 0;
+        k[r] = act ? (uint32_t)keys_in[p] : 0; v[r] = act ? vals_in[p] : 0; mk[r] = act ? msk_in[p] : (uint16_t)0;
     }
 #pragma unroll
     for (int r = 0; r < RADIX_ROUNDS; ++r) {
@@ -502,7 +550,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const K* __restrict__ key
         if (wbeg + (uint64_t)r * 64 + lane < cend) {
             const uint32_t dgt = (k[r] >> shift) & mask;
             const uint32_t lp = s_cnt[w][dgt] + rk[r];
-            s_key[lp] = (K)k[r]; s_val[lp] = v[r];
+            s_key[lp] = (K)k[r]; s_val[lp] = v[r]; s_msk[lp] = mk[r];
         }
     }
     __syncthreads();
@@ -511,7 +559,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const K* __restrict__ key
         const uint32_t key = s_key[i];
         const uint32_t dgt = (key >> shift) & mask;
         const uint32_t dst = s_gbase[dgt] + (i - s_start[dgt]);
-        keys_out[dst] = (K)key; vals_out[dst] = s_val[i];
+        keys_out[dst] = (K)key; vals_out[dst] = s_val[i]; msk_out[dst] = s_msk[i];
     }
 }
 
@@ -547,9 +595,9 @@ namespace trgl {
 uint32_t setup_num_blocks(uint32_t n) { return (n + SETUP_THREADS - 1) / SETUP_THREADS; }
 
 void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc* draws_dev, int draw_idx, uint32_t n,
-                  TriRec* recs, uint32_t* cnt, uint2* tilebox, DevStats* stats, uint32_t* blk_sums, uint32_t blk_base) {
+                  TriRec* recs, TriW* recs_w, uint32_t* cnt, uint2* tilebox, DevStats* stats, uint32_t* blk_sums, uint32_t blk_base) {
     if (!n) return;
-    hipLaunchKernelGGL(k_setup, dim3(setup_num_blocks(n)), dim3(SETUP_THREADS), 0, s, fp, draws_dev, draw_idx, recs, cnt, tilebox,
+    hipLaunchKernelGGL(k_setup, dim3(setup_num_blocks(n)), dim3(SETUP_THREADS), 0, s, fp, draws_dev, draw_idx, recs, recs_w, cnt, tilebox,
                        stats, blk_sums, blk_base);
 }
 
@@ -558,15 +606,15 @@ void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, 
 }
 
 void launch_expand(hipStream_t s, const FrameParams& fp, uint32_t first, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* blk_sums,
-                   const uint32_t* chunk_off, uint32_t blk_base, const uint2* tilebox, void* keys, bool key16, uint32_t* vals,
+                   const uint32_t* chunk_off, uint32_t blk_base, const uint2* tilebox, void* keys, bool key16, uint32_t* vals, uint16_t* bmask,
                    const unsigned long long* pairs_total, uint32_t cap) {
     if (!n) return;
     if (key16)
         hipLaunchKernelGGL(k_expand<uint16_t>, dim3(setup_num_blocks(n)), dim3(SETUP_THREADS), 0, s, fp, first, n, tiles_x, cnt, blk_sums, chunk_off,
-                           blk_base, tilebox, (uint16_t*)keys, vals, pairs_total, cap);
+                           blk_base, tilebox, (uint16_t*)keys, vals, bmask, pairs_total, cap);
     else
         hipLaunchKernelGGL(k_expand<uint32_t>, dim3(setup_num_blocks(n)), dim3(SETUP_THREADS), 0, s, fp, first, n, tiles_x, cnt, blk_sums, chunk_off,
-                           blk_base, tilebox, (uint32_t*)keys, vals, pairs_total, cap);
+                           blk_base, tilebox, (uint32_t*)keys, vals, bmask, pairs_total, cap);
 }
 
 uint32_t radix_num_workers(uint32_t P) { return (P + RADIX_CHUNK - 1) / RADIX_CHUNK; }   // = blocks of a pass
@@ -574,21 +622,21 @@ uint32_t radix_num_workers(uint32_t P) { return (P + RADIX_CHUNK - 1) / RADIX_CH
 // The pair count of the flush stays on the device (`pairs_total`): grids cover `cap`, the capacity of the pair buffers,
 // and blocks past the last pair do nothing, so the host never has to wait for the count before it can queue these.
 template <typename K>
-static void radix_pass_t(hipStream_t s, const K* keys_in, const uint32_t* vals_in, K* keys_out, uint32_t* vals_out,
+static void radix_pass_t(hipStream_t s, const K* keys_in, const uint32_t* vals_in, const uint16_t* msk_in, K* keys_out, uint32_t* vals_out, uint16_t* msk_out,
                          const unsigned long long* pairs_total, uint32_t cap, int shift, int bits, uint32_t* hist, uint32_t* scan_tmp) {
     uint32_t nblk = radix_num_workers(cap);
     hipLaunchKernelGGL(k_radix_hist<K>, dim3(nblk), dim3(256), 0, s, keys_in, pairs_total, cap, shift, bits, nblk, hist);
     hipLaunchKernelGGL(k_radix_scan_rows, dim3(1u << bits), dim3(ROWSCAN_THREADS), 0, s, hist, nblk, scan_tmp);
-    hipLaunchKernelGGL(k_radix_scatter<K>, dim3(nblk), dim3(256), 0, s, keys_in, vals_in, pairs_total, cap, shift, bits, nblk, hist, scan_tmp,
-                       keys_out, vals_out);
+    hipLaunchKernelGGL(k_radix_scatter<K>, dim3(nblk), dim3(256), 0, s, keys_in, vals_in, msk_in, pairs_total, cap, shift, bits, nblk, hist, scan_tmp,
+                       keys_out, vals_out, msk_out);
 }
 
-void launch_radix_pass(hipStream_t s, const void* keys_in, const uint32_t* vals_in, void* keys_out,
-                       uint32_t* vals_out, bool key16, const unsigned long long* pairs_total, uint32_t cap, int shift, int bits,
+void launch_radix_pass(hipStream_t s, const void* keys_in, const uint32_t* vals_in, const uint16_t* msk_in, void* keys_out,
+                       uint32_t* vals_out, uint16_t* msk_out, bool key16, const unsigned long long* pairs_total, uint32_t cap, int shift, int bits,
                        uint32_t* hist, uint32_t* scan_tmp) {
     if (!cap) return;
-    if (key16) radix_pass_t<uint16_t>(s, (const uint16_t*)keys_in, vals_in, (uint16_t*)keys_out, vals_out, pairs_total, cap, shift, bits, hist, scan_tmp);
-    else radix_pass_t<uint32_t>(s, (const uint32_t*)keys_in, vals_in, (uint32_t*)keys_out, vals_out, pairs_total, cap, shift, bits, hist, scan_tmp);
+    if (key16) radix_pass_t<uint16_t>(s, (const uint16_t*)keys_in, vals_in, msk_in, (uint16_t*)keys_out, vals_out, msk_out, pairs_total, cap, shift, bits, hist, scan_tmp);
+    else radix_pass_t<uint32_t>(s, (const uint32_t*)keys_in, vals_in, msk_in, (uint32_t*)keys_out, vals_out, msk_out, pairs_total, cap, shift, bits, hist, scan_tmp);
 }
 
 void launch_bounds(hipStream_t s, const void* keys, bool key16, const unsigned long long* pairs_total, uint32_t cap,

@@ -7,7 +7,7 @@ namespace trgl {
 
 uint32_t setup_num_blocks(uint32_t n);      // blocks of 256 triangles of one draw (k_setup and k_expand use the same)
 void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc* draws_dev, int draw_idx, uint32_t n,
-                  TriRec* recs, uint32_t* cnt, uint2* tilebox, DevStats* stats, uint32_t* blk_sums, uint32_t blk_base);
+                  TriRec* recs, TriW* recs_w, uint32_t* cnt, uint2* tilebox, DevStats* stats, uint32_t* blk_sums, uint32_t blk_base);
 // chunk_off[c] = pairs before setup block 16c; *total64 = all pairs of the flush
 void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, uint32_t* chunk_off, unsigned long long* total64);
 
@@ -15,23 +15,26 @@ void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, 
 // expand / radix / bounds read the flush's pair count from device memory and cover `cap` (the capacity of the pair buffers)
 // with their grids; they do nothing when the count exceeds it (the host then grows the buffers and queues them again)
 void launch_expand(hipStream_t s, const FrameParams& fp, uint32_t first, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* blk_sums,
-                   const uint32_t* chunk_off, uint32_t blk_base, const uint2* tilebox, void* keys, bool key16, uint32_t* vals,
+                   const uint32_t* chunk_off, uint32_t blk_base, const uint2* tilebox, void* keys, bool key16, uint32_t* vals, uint16_t* bmask,
                    const unsigned long long* pairs_total, uint32_t cap);
 
 uint32_t radix_num_workers(uint32_t P);
 // key16: the keys (tile indices) are 16-bit words (frames of at most 65536 tiles), else 32-bit
-void launch_radix_pass(hipStream_t s, const void* keys_in, const uint32_t* vals_in, void* keys_out,
-                       uint32_t* vals_out, bool key16, const unsigned long long* pairs_total, uint32_t cap, int shift, int bits,
+// (the 4x4 block mask of every pair travels with it)
+void launch_radix_pass(hipStream_t s, const void* keys_in, const uint32_t* vals_in, const uint16_t* msk_in, void* keys_out,
+                       uint32_t* vals_out, uint16_t* msk_out, bool key16, const unsigned long long* pairs_total, uint32_t cap, int shift, int bits,
                        uint32_t* hist, uint32_t* scan_tmp);
 
 void launch_bounds(hipStream_t s, const void* keys, bool key16, const unsigned long long* pairs_total, uint32_t cap,
                    uint32_t* tile_start, uint32_t* tile_end);
 
 uint32_t owned_tiles(const FrameParams& fp);       // tiles of the rows this context owns (strip or interleaved bands)
-uint32_t raster_max_items(const FrameParams& fp, uint64_t pairs, uint32_t split_len);
-void launch_raster(hipStream_t s, const FrameParams& fp, int kind, bool all_well_scaled, const TriRec* recs, const uint32_t* vals,
+uint32_t raster_max_items(const FrameParams& fp);   // work items (workgroups of k_raster) of a flush, at most
+// item_stats: 16 x uint64 per work item (one partial of the counters per wave)
+void launch_raster(hipStream_t s, const FrameParams& fp, int kind, bool all_well_scaled, const TriRec* recs, const TriW* recs_w,
+                   const uint32_t* vals, const uint16_t* bmask,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
-                   const DevTexture* tex, DevStats* stats, uint32_t split_len, uint32_t max_items, uint32_t* items,
+                   const DevTexture* tex, DevStats* stats, uint32_t max_items, uint32_t* items,
                    uint32_t* n_items, unsigned long long* item_stats, hipEvent_t ev_before = nullptr,
                    hipEvent_t ev_after = nullptr);     // optional events recorded right around the k_raster launch
 

@@ -50,7 +50,7 @@ struct trgl_ctx {
     std::vector<StageChunk> stage;
     int stage_hold = 0;                 // >0 while a draw call has staged data that no DrawDesc references yet
 
-    TriRec* recs = nullptr; uint32_t* cnt = nullptr; uint2* tilebox = nullptr;
+    TriRec* recs = nullptr; TriW* recs_w = nullptr; uint32_t* cnt = nullptr; uint2* tilebox = nullptr;
     // a flush whose first half (setup + binning) has run and whose raster half is still to be launched (trgl_flush_begin)
     struct { bool active = false; FrameParams fp; int flush_kind = 0; uint32_t cap = 0; int cur = 0; uint64_t N = 0; bool binned = false; } rp;
     hipEvent_t ev_pairs = nullptr;      // recorded behind the copy of the flush's pair count into pinned memory
@@ -59,7 +59,7 @@ struct trgl_ctx {
     uint32_t* blk_sums = nullptr; size_t cap_blk = 0;       // pairs per setup block of 256 triangles
     uint32_t* chunk_off = nullptr; size_t cap_chunk = 0;    // pairs before every 16th setup block
     size_t cap_tris = 0;
-    uint32_t* keys[2] = { nullptr, nullptr }; uint32_t* vals[2] = { nullptr, nullptr };
+    uint32_t* keys[2] = { nullptr, nullptr }; uint32_t* vals[2] = { nullptr, nullptr }; uint16_t* bmask[2] = { nullptr, nullptr };
     size_t cap_pairs = 0;
     uint32_t* hist = nullptr; size_t cap_hist = 0;
     uint32_t* scan_tmp = nullptr; size_t cap_scan = 0;
@@ -110,7 +110,7 @@ static int reset_dev_stats(trgl_ctx* c) {
     s.zmin_key = zkey_host(std::numeric_limits<double>::infinity());
     s.zmax_key = zkey_host(-std::numeric_limits<double>::infinity());
     s.min_x = INT32_MAX; s.min_y = INT32_MAX; s.max_x = INT32_MIN; s.max_y = INT32_MIN;
-    s.pairs_total = 0; s.literal_tris = 0; s.nonempty_tiles = 0;
+    s.pairs_total = 0; s.literal_tris = 0; s.reserved0 = 0;
     s.zero_pos_key = s.zero_neg_key = TRGL_ZERO_KEY_EMPTY;
     s.zero_locked = 0; s.zero_sign = 0;
     for (int k = 0; k < 16; ++k) s.dbg[k] = 0;
@@ -162,7 +162,7 @@ int trgl_create(int device, int width, int height, int bpp, trgl_ctx** out) {
     CRE(hipMemset(c->tex_dev, 0, sizeof(c->tex_host)));
     CRE(hipMalloc((void**)&c->tile_start, ntiles * 8));        // tile_start[ntiles] followed by tile_end[ntiles]: one memset per flush
     c->tile_end = c->tile_start + ntiles;
-    CRE(hipMalloc((void**)&c->n_items, 8));                     // [0] work items of the flush, [1] its tiles with triangles
+    CRE(hipMalloc((void**)&c->n_items, 8));                     // work items of the flush
     CRE(hipMemset(c->n_items, 0, 8));                           // k_fold_stats leaves it at 0 for the next flush
     CRE(hipMalloc((void**)&c->draws_dev, sizeof(DrawDesc) * TRGL_MAX_DRAWS));
     CRE(hipHostMalloc((void**)&c->draws_pinned, sizeof(DrawDesc) * TRGL_MAX_DRAWS));
@@ -184,7 +184,7 @@ int trgl_destroy(trgl_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& s : c->stage) (void)hipFree(s.base);
     for (int i = 0; i < TRGL_MAX_TEXTURES; ++i) if (c->tex_host[i].data) (void)hipFree((void*)c->tex_host[i].data);
-    void* ptrs[] = { c->fb, c->zb, c->tex_dev, c->recs, c->cnt, c->idbuf, c->pp_out, c->blk_sums, c->chunk_off, c->tilebox, c->keys[0], c->keys[1], c->vals[0],
+    void* ptrs[] = { c->fb, c->zb, c->tex_dev, c->recs, c->recs_w, c->bmask[0], c->bmask[1], c->cnt, c->idbuf, c->pp_out, c->blk_sums, c->chunk_off, c->tilebox, c->keys[0], c->keys[1], c->vals[0],
                      c->vals[1], c->hist, c->scan_tmp, c->tile_start, c->draws_dev, c->stats_dev, c->items, c->n_items, c->item_stats };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->draws_pinned) (void)hipHostFree(c->draws_pinned);
@@ -273,6 +273,7 @@ static int vary_count(int kind) {
     case TRGL_SHADER_GOURAUD: return TRGL_VARY_GOURAUD;
     case TRGL_SHADER_PHONG: return TRGL_VARY_PHONG;
     case TRGL_SHADER_EYE: return TRGL_VARY_EYE;
+    case TRGL_SHADER_CHECKER: return TRGL_VARY_CHECKER;
     default: return 0;
     }
 }
@@ -307,6 +308,7 @@ int trgl_draw(trgl_ctx* c, int kind, const trgl_uniforms* u, const double* clip,
     int K = vary_count(kind);
     if (K && !vary) return fail(c, TRGL_E_INVALID, "trgl_draw: this shader kind needs varyings");
     if ((kind == TRGL_SHADER_PHONG || kind == TRGL_SHADER_EYE) && !u) return fail(c, TRGL_E_INVALID, "trgl_draw: PHONG/EYE need uniforms");
+    if (kind == TRGL_SHADER_CHECKER && (!u || u->reserved < 1)) return fail(c, TRGL_E_INVALID, "trgl_draw: CHECKER needs uniforms with reserved = cells >= 1");
     if (mem_kind != TRGL_MEM_HOST && mem_kind != TRGL_MEM_DEVICE) return fail(c, TRGL_E_INVALID, "trgl_draw: bad mem_kind");
     if (c->queued_tris + n > 0xffffffffull) { int r = trgl_flush(c); if (r) return r; }
     if (n > 0xffffffffull) return fail(c, TRGL_E_UNSUPPORTED, "trgl_draw: more than 2^32-1 triangles in one draw");
@@ -440,7 +442,7 @@ static int queue_binning(trgl_ctx* c, const FrameParams& fp, uint32_t cap, int* 
     uint32_t blk_base = 0;
     const bool key16 = ntiles <= 65536;        // tile indices as 16-bit keys: a third less traffic in every binning kernel
     for (auto& d : c->draws) {
-        launch_expand(s, fp, d.first, d.n, c->tiles_x, c->cnt, c->blk_sums, c->chunk_off, blk_base, c->tilebox, c->keys[0], key16, c->vals[0], pairs_dev, cap);
+        launch_expand(s, fp, d.first, d.n, c->tiles_x, c->cnt, c->blk_sums, c->chunk_off, blk_base, c->tilebox, c->keys[0], key16, c->vals[0], c->bmask[0], pairs_dev, cap);
         blk_base += setup_num_blocks(d.n);
     }
     int key_bits = 1; while ((size_t(1) << key_bits) < ntiles) ++key_bits;
@@ -451,7 +453,7 @@ static int queue_binning(trgl_ctx* c, const FrameParams& fp, uint32_t cap, int* 
     if ((r = grow(c, c->scan_tmp, c->cap_scan, 256 + 16))) return r;   // the digit totals of a pass (k_radix_scan_rows)
     int cur = 0;
     for (int ps = 0; ps < passes; ++ps) {
-        launch_radix_pass(s, c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1], key16, pairs_dev, cap, ps * bits_per, bits_per,
+        launch_radix_pass(s, c->keys[cur], c->vals[cur], c->bmask[cur], c->keys[cur ^ 1], c->vals[cur ^ 1], c->bmask[cur ^ 1], key16, pairs_dev, cap, ps * bits_per, bits_per,
                           c->hist, c->scan_tmp);
         cur ^= 1;
     }
@@ -468,6 +470,7 @@ static int grow_pairs(trgl_ctx* c, size_t need) {
     for (int k = 0; k < 2; ++k) {
         if ((r = realloc_dev(c, (void**)&c->keys[k], ncap * 4))) return r;
         if ((r = realloc_dev(c, (void**)&c->vals[k], ncap * 4))) return r;
+        if ((r = realloc_dev(c, (void**)&c->bmask[k], ncap * 2))) return r;
     }
     c->cap_pairs = ncap;
     return TRGL_OK;
@@ -518,6 +521,7 @@ int trgl_flush_begin(trgl_ctx* c) {
         if (N > c->cap_tris) {
             size_t ncap = N + N / 4 + 1024;
             if ((r = realloc_dev(c, (void**)&c->recs, ncap * sizeof(TriRec)))) return r;
+            if ((r = realloc_dev(c, (void**)&c->recs_w, ncap * sizeof(TriW)))) return r;
             if ((r = realloc_dev(c, (void**)&c->cnt, ncap * 4))) return r;
             if ((r = realloc_dev(c, (void**)&c->tilebox, ncap * sizeof(uint2)))) return r;
             c->cap_tris = ncap;
@@ -532,13 +536,13 @@ int trgl_flush_begin(trgl_ctx* c) {
         {
             uint32_t blk_base = 0;
             for (size_t i = 0; i < c->draws.size(); ++i) {
-                launch_setup(s, fp, c->draws_dev, (int)i, c->draws[i].n, c->recs, c->cnt, c->tilebox, c->stats_dev, c->blk_sums, blk_base);
+                launch_setup(s, fp, c->draws_dev, (int)i, c->draws[i].n, c->recs, c->recs_w, c->cnt, c->tilebox, c->stats_dev, c->blk_sums, blk_base);
                 blk_base += setup_num_blocks(c->draws[i].n);
             }
         }
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
         launch_chunk_spine(s, c->blk_sums, nblk, c->chunk_off, &c->stats_dev->pairs_total);
-        HIPCHK(c, hipMemcpyAsync(&c->stats_pinned->pairs_total, &c->stats_dev->pairs_total, 24, hipMemcpyDeviceToHost, s));   // + literal_tris, nonempty_tiles
+        HIPCHK(c, hipMemcpyAsync(&c->stats_pinned->pairs_total, &c->stats_dev->pairs_total, 16, hipMemcpyDeviceToHost, s));   // + literal_tris
         HIPCHK(c, hipEventRecord(c->ev_pairs, s));
         HIPCHK(c, hipMemsetAsync(c->tile_start, 0, ntiles * 8, s));                // tile_start and tile_end
         cap = (uint32_t)c->cap_pairs;
@@ -583,34 +587,15 @@ int trgl_flush_end(trgl_ctx* c) {
     // valid addresses anyway
     const TriRec* recs_arg = c->recs ? c->recs : reinterpret_cast<const TriRec*>(c->tile_start);
     const uint32_t* vals_arg = (P && c->vals[cur]) ? c->vals[cur] : c->tile_start;
-    // A lone wave needs ~1-3 us per list entry (one long dependent fp64 chain); throughput comes from many waves.
-    // So lists longer than twice the mean list length (at least 8 entries) are cut into 2..16 row bands: dense
-    // uniform scenes (C4: 1100 entries in every tile) never split, sparse or uneven ones (meshes) get parallelism.
-    uint64_t strip_tiles = owned_tiles(fp);
-    // "Mean" is over the tiles that HAVE triangles when the previous flush told us how many those were (a mesh covers a quarter of
-    // the screen: the mean over all tiles is four times too small and cut nearly every covered tile of the 4096^2 head frame into
-    // bands, each walking the same list).  The count came over with the pair count (DevStats::nonempty_tiles); 0 = not known yet.
-    if (N) {
-        const uint64_t hint = c->stats_pinned->nonempty_tiles;
-        if (hint && hint < strip_tiles) strip_tiles = hint;
-    }
-    uint32_t split_len = 8;
-    if (strip_tiles && 2 * (uint64_t)P / strip_tiles > split_len) split_len = (uint32_t)(2 * (uint64_t)P / strip_tiles);
-    // ... unless the strip has fewer (covered) tiles than the GPU has wave slots (a rank of a multi-GPU run, a small frame): then
-    // bands are what fills the machine, and the target is about one item per slot (16 waves per CU).
-    const uint64_t wave_slots = (uint64_t)c->num_cus * 16;
-    if (strip_tiles && strip_tiles < wave_slots) {
-        const uint64_t fill_len = 3 * (uint64_t)P / (2 * wave_slots);
-        if (fill_len < split_len) split_len = (uint32_t)(fill_len > 8 ? fill_len : 8);
-    }
-    if (const char* e = std::getenv("TRGL_SPLIT_LEN")) { const long v = std::atol(e); if (v > 0) split_len = (uint32_t)v; }   // experiments only
-    const uint32_t max_items = raster_max_items(fp, P, split_len);
+    const uint16_t* bmask_arg = (P && c->bmask[cur]) ? c->bmask[cur] : reinterpret_cast<const uint16_t*>(c->tile_start);
+    // one work item (a workgroup of four block waves) per row of blocks of every owned tile
+    const uint32_t max_items = raster_max_items(fp);
     if ((r = grow(c, c->items, c->cap_items, (size_t)max_items + 64))) return r;
-    if ((r = grow(c, c->item_stats, c->cap_item_stats, ((size_t)max_items + 64) * 4))) return r;
+    if ((r = grow(c, c->item_stats, c->cap_item_stats, ((size_t)max_items + 64) * 16))) return r;
     // k_setup counted the triangles that are not well scaled (it came over with the pair count): without any, the kernel without the literal path
     const bool all_well_scaled = N == 0 || c->stats_pinned->literal_tris == 0;
-    launch_raster(s, fp, flush_kind, all_well_scaled, recs_arg, vals_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev,
-                  split_len, max_items, c->items, c->n_items, c->item_stats,
+    launch_raster(s, fp, flush_kind, all_well_scaled, recs_arg, c->recs_w, vals_arg, bmask_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev,
+                  max_items, c->items, c->n_items, c->item_stats,
                   c->profiling ? c->ev[4] : nullptr, c->profiling ? c->ev[5] : nullptr);
     if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[3], s)); c->events_pending = true; }
     HIPCHK(c, hipGetLastError());

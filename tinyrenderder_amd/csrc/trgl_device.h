@@ -4,38 +4,50 @@
 //   fb      uint8  [H][W][bpp]      TGAImage layout, row y=0 first (tgaimage.cpp:32-39)
 //   zb      double [H][W]           the reference's global zbuffer (our_gl.cpp:15,72-74)
 //   recs    TriRec [N]              one 128-B line per submitted triangle, written by setup
+//   recs_w  TriW   [N]              1/w of the vertices, for draws whose fragments need perspective-correct barycentrics
 //   cnt/off uint32 [N]              tiles overlapped per triangle and its exclusive scan
-//   keys/vals uint32 [P] x2         (tile id, triangle id) pairs, ping-pong for the radix passes
+//   keys/vals/bmask [P] x2          (tile id, triangle id, 4x4 mask of the tile's blocks the bbox reaches) triples, ping-pong
+//                                   for the radix passes
 //   tile_start/tile_end uint32[T]   per-tile slice of the sorted pair list
 #pragma once
 #include <stdint.h>
 #include "../../include/trgl.h"
 
-#define TRGL_TILE      32          // tile is TILE x TILE pixels, owned by ONE wavefront
+#define TRGL_TILE      32          // tile is TILE x TILE pixels = 4 x 4 BLOCKS of 8 x 8 pixels; one wavefront owns one block
 #define TRGL_TILE_LOG2 5
 #define TRGL_TILE_PIX  (TRGL_TILE * TRGL_TILE)
-#ifndef TRGL_WAVES_PER_BLOCK
-#define TRGL_WAVES_PER_BLOCK 4     // a raster workgroup is 4 work items (2 and 8 waves per workgroup: 3 % slower on C4)
-#endif
+#define TRGL_BLOCK_LOG2 3          // a block is 8 x 8 pixels = the 64 lanes of a wavefront (lane = 8 * row + column)
 #define TRGL_MAX_DRAWS 64          // draws per flush (each with its own shader kind + uniforms)
 
 // Per-triangle setup record: everything the pixel loop needs, hoisted exactly as SURVEY §8(a) A4/A6
 // allows (same operations on the same operands as our_gl.cpp:77-86,168-170, so bit-identical).
+// Chunks (16 B) 0-5 are what a block's scan needs as wave-uniform constants (scalar loads: dwordx16 + dwordx8) and what the
+// per-block cull test reads per candidate lane; chunks 3 and 5-7 are gathered per lane when deferred fragments are resolved.
 struct alignas(128) TriRec {
     double ax, ay;            // screen[0]                       (our_gl.cpp:117-121)
     double s0x, s0y;          // C.x - A.x, B.x - A.x            (our_gl.cpp:78)
     double s1x, s1y;          // C.y - A.y, B.y - A.y            (our_gl.cpp:79)
+    double c0;                // depth plane of the early depth test: every covered pixel of the triangle has
+                              //   z > c0 + (ax - x) g1 + (ay - y) g2   (k_setup; c0 = -inf, g = 0: no test)
     double uz;                // s0x*s1y - s0y*s1x = cross().z   (our_gl.cpp:80, geometry.h:147)
+    double g1, g2;
+    uint16_t bx0, by0, bx1, by1;   // clamped pixel bbox, inclusive (our_gl.cpp:130-133)
+    uint32_t color;           // FLAT packed BGRA (GOURAUD reads its base colour through `dl`)
+    uint32_t dl;              // bit 31: not "well scaled" (literal divisions, see k_setup) | draw index << 24 | triangle index inside its draw (< 2^24)
     double ruz;               // RN(1/uz) when the triangle is "well scaled" (see setup), else 0:
                               // lets the pixel loop divide by uz with FMAs, bit-identically
     double z0, z1, z2;        // NDC z of the three vertices     (our_gl.cpp:156-158)
-    double iw0, iw1, iw2;     // |w|>1e-12 ? 1/w : 0             (our_gl.cpp:168-170)
-    uint16_t bx0, by0, bx1, by1;   // clamped pixel bbox, inclusive (our_gl.cpp:130-133)
-    uint32_t color;           // FLAT packed BGRA (GOURAUD reads its base colour through `dl`)
-    uint32_t dl;              // draw index << 24 | triangle index inside its draw (< 2^24)
 };
 static_assert(sizeof(TriRec) == 128, "TriRec must be one 128-B line");
 #define TRGL_DRAW_MAX_TRIS (1u << 24)   // triangles per DrawDesc; trgl_draw splits larger submissions
+#define TRGL_DL_LITERAL   0x80000000u
+#define TRGL_DL_DRAW(dl)  (((dl) >> 24) & (TRGL_MAX_DRAWS - 1))
+#define TRGL_DL_LOCAL(dl) ((dl) & 0xffffffu)
+#define TRGL_DL_ID(dl)    ((dl) & 0x3fffffffu)          // draw << 24 | local: what the visibility buffer holds (~0u = no owner)
+
+// 1/w of the three vertices, |w|>1e-12 ? 1/w : 0 (our_gl.cpp:168-170): read only where perspective-correct barycentrics are
+// needed (GOURAUD, PHONG, EYE fragments), so it lives beside the record and is written only for draws of those kinds.
+struct alignas(32) TriW { double iw0, iw1, iw2, pad; };
 
 struct DevTexture {
     const uint8_t* data;
@@ -62,8 +74,7 @@ struct DevStats {
     unsigned long long pairs_total;      // written by the scan spine (implementation traffic)
     unsigned long long literal_tris;     // triangles of the flush in flight that are not "well scaled" (k_setup adds, k_fold_stats clears); copied to the
                                          // host together with pairs_total: a flush without any runs the raster kernel that has no literal path
-    unsigned long long nonempty_tiles;   // tiles with triangles in the PREVIOUS flush (k_make_items counts, k_fold_stats publishes): rides with the
-                                         // two counts above and tells the host how long a tile's list has to be before it is cut into row bands
+    unsigned long long reserved0;
     // std::min/std::max keep the FIRST of two equal values (our_gl.cpp:197-198), and +0.0 == -0.0:
     // when the z range ends in a zero its sign is that of the first zero written, in the reference's
     // order (triangle, x, y).  Keys = tri<<32 | x<<16 | y of the first +0 / -0 fragment of this flush.
