@@ -12,14 +12,9 @@ L.trgl_draw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
 assert L.trgl_draw(h, 0, None, dclip.data_ptr(), None, dcol.data_ptr(), N, 1) == 0
 out = (C.c_ulonglong * 16)(); L.trgl_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
 assert L.trgl_debug_counters(h, out) == 0
-names = ["triangles scanned (slots read)", "blocks visited", "blocks with a covered pixel inside the bbox (before the depth-plane test)",
-         "lanes of visited blocks inside the bbox", "list entries (pairs)", "visited blocks without a covered pixel",
-         "blocks dropped by the per-lane masks", "... of which wrote a pixel (must be 0)",
-         "covered lanes (before the depth-plane test)", "... that write their pixel", "blocks with covered pixels that write nothing",
-         "... all of whose covered pixels the per-pixel depth-plane test kills (no divisions)", "lanes the depth-plane test would wrongly kill (must be 0)",
-         "visited blocks that end at the depth-plane test (no lane inside the bbox survives it)"
-         ]
+names = ["candidates (list entries whose bbox reaches the wave's block)", "survivors of the cull = visits", "visits", "lanes of visits inside (bbox n block)",
+         "visits with a covered lane (deferred)", "covered lanes that survive the depth plane (deferred fragments)", "resolves", "lanes resolved",
+         "fragments written"]
 for n, v in zip(names, out): print(f"{n:82s} {v:>12d}  per triangle {v / N:.3f}")
-# the diagnostic build counts what the depth-plane test WOULD skip and still runs it; the production kernel:
-print(f"{'production kernel: blocks that run the three divisions':82s} {out[2] - out[11]:>12d}  per triangle {(out[2] - out[11]) / N:.3f}")
-print(f"{'production kernel: visited blocks that end before the divisions':82s} {out[1] - out[2] + out[11]:>12d}  per triangle {(out[1] - out[2] + out[11]) / N:.3f}")
+print(f"{'lanes per resolve':82s} {out[7] / max(out[6], 1):>12.2f}")
+print(f"{'covered lanes per covered visit':82s} {out[5] / max(out[4], 1):>12.2f}")

@@ -24,6 +24,20 @@ __device__ __forceinline__ double vmax(double a, double b) { double r; asm("v_ma
 // v_min3_f32 / v_max_f32 as single instructions (a NaN operand is skipped)
 __device__ __forceinline__ float fmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float fmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// maximum over the 64 lanes, in every lane (NaN operands are skipped by v_max_f32)
+__device__ __forceinline__ float wave_max_f32(float v) {
+    float t;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(t) : "v"(v)); v = t;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(t) : "v"(v)); v = t;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=&v"(t) : "v"(v)); v = t;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=&v"(t) : "v"(v)); v = t;
+    // every lane now holds the maximum of its row of 16: combine the four rows through the scalar side
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return fmax2(fmax2(r0, r1), fmax2(r2, r3));
+}
 // double -> float rounded towards +inf / -inf (NaN stays NaN): bounds that stay bounds in single precision
 __device__ __forceinline__ float f32_up(double d) {
     float f = (float)d;
@@ -283,6 +297,7 @@ constexpr int RING = 128;                           // candidate ring of a wave 
 #endif
 
 typedef const __attribute__((address_space(4))) TriRec CRec;      // records through the scalar cache
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
 // The scan constants of one triangle, wave-uniform (SGPRs): chunks 0-5 of its record.
 struct TriScan {
@@ -312,6 +327,7 @@ struct BlockState {
     double pux, puy; uint32_t ptri;
     uint32_t frags; double zmin, zmax;
     int x, y;
+    us2 xy;                 // x | y << 16 as two 16-bit words (the bbox test of a visit is packed 16-bit arithmetic)
 #ifdef TRGL_DEBUG_COUNTERS
     unsigned long long dbg[16];    // work counters of the diagnostic build (profiles/raster_counters.py); [8] is summed over the lanes
 #endif
@@ -389,13 +405,6 @@ __device__ __forceinline__ void resolve(BlockState& S, unsigned long long pend, 
             }
         }
     }
-}
-
-// 64-bit lane mask of the rows [ly0, ly1] x columns [lx0, lx1] of the block (lane = 8 row + column); scalar arithmetic only
-__device__ __forceinline__ unsigned long long rect_mask(int lx0, int ly0, int lx1, int ly1) {
-    const uint32_t cols = (((2u << lx1) - (1u << lx0)) & 0xffu) * 0x01010101u;
-    const unsigned long long all = ((unsigned long long)cols << 32) | cols;
-    return all & (~0ull >> (8 * (7 - ly1))) & (~0ull << (8 * ly0));
 }
 
 // Rows of a cleared tile without triangles: the clear values, row-contiguous (this is the whole kernel on a clear-only frame, the
@@ -498,6 +507,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
 
     BlockState S;
     S.x = X0 + (lane & 7); S.y = Y0 + (lane >> 3);
+    S.xy = __builtin_bit_cast(us2, (uint32_t)S.x | ((uint32_t)S.y << 16));
     const bool owned = S.x < fp.W && S.y < fp.H && S.y >= fp.strip_y0 && S.y < fp.strip_y1;
     const size_t pix = (size_t)S.x + (size_t)S.y * fp.W;
     S.pxc = (double)S.x + 0.5; S.pyc = (double)S.y + 0.5;
@@ -520,14 +530,19 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
     uint32_t head = 0, cnt = 0;                           // ring: `cnt` candidates wait from position `head` on
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     // the list, 64 entries per step; the entries of the next step are requested before the candidates of this one are processed
+    // (loads without a branch around them - clamped index, mask cleared past the end - so that the wait for THIS step's entries can
+    // leave the next step's loads in flight)
     uint32_t tri_n = 0, msk_n = 0;
-    if (beg + lane < end) { tri_n = vals[beg + lane]; msk_n = bmask[beg + lane]; }
+    if (beg < end) {
+        const uint32_t p = min(beg + lane, end - 1);
+        tri_n = vals[p]; msk_n = (beg + lane < end) ? bmask[p] : 0u;
+    }
     for (uint32_t p0 = beg; p0 < end; p0 += 64) {
         const uint32_t tri_c = tri_n, msk_c = msk_n;
         {
-            const uint32_t p = p0 + 64 + lane;
-            tri_n = 0; msk_n = 0;
-            if (p < end) { tri_n = vals[p]; msk_n = bmask[p]; }
+            const uint32_t pn = p0 + 64 + lane, p = min(pn, end - 1);
+            tri_n = vals[p]; msk_n = bmask[p];
+            if (pn >= end) msk_n = 0;
         }
         const bool cand = (msk_c >> kblk) & 1u;           // (entries past the end carry an empty mask)
         const unsigned long long cb = __ballot(cand);
@@ -546,12 +561,12 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
             // ---- cull: lane = candidate ------------------------------------------------------------------------------
             // largest stored depth of the block (deferred fragments only lower depths later: a stale maximum stays a bound;
             // a pixel holding NaN can never be written again, v_max skips it)
-            double zmaxb = S.z;
-            for (int o = 32; o; o >>= 1) zmaxb = vmax(zmaxb, __shfl_xor(zmaxb, o));
+            // (as a float rounded up: six v_max_f32 with DPP / permlane operands instead of 64-bit shuffles through LDS)
+            const double zmaxb = (double)wave_max_f32(f32_up(S.z));
             bool keep = (uint32_t)lane < n;
             if (keep) {
                 const double2* q = reinterpret_cast<const double2*>(recs + tri);
-                const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+                const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q6 = q[6], q7 = q[7];
                 const uint4 q5 = reinterpret_cast<const uint4*>(q)[5];
                 if (ALLWS || !(q5.w & TRGL_DL_LITERAL)) {
                     const double ax = q0.x, ay = q0.y, s0x = q1.x, s0y = q1.y, s1x = q2.x, s1y = q2.y, c0 = q3.x, uz = q3.y, g1 = q4.x, g2 = q4.y;
@@ -577,61 +592,137 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                     // (depth)  every covered pixel's z is above the plane c0 + (ax - x) g1 + (ay - y) g2 (k_setup), whose minimum
                     // over the rectangle again sits at a corner; if even that is not below the block's largest stored depth,
                     // no pixel of the block passes the strict `<` of :165.  NaN compares false = keep.
+                    // The plane reaches below the triangle's own depths outside the triangle; a covered pixel also has b_i >= 0 and
+                    // b0 + b1 + b2 = 1 +- 2^-50, hence z >= min(z0, z1, z2) - 2^-40 max|z_i|: the larger of the two bounds counts.
                     const double xz = g1 >= 0.0 ? xhi : xlo, yz = g2 >= 0.0 ? yhi : ylo;
-                    const double zlo = __builtin_fma(ax - xz, g1, __builtin_fma(ay - yz, g2, c0));
-                    if (uxm > ma || uym > mb || usm < uz - (ma + mb) || zlo >= zmaxb) keep = false;
+                    const double zpl = __builtin_fma(ax - xz, g1, __builtin_fma(ay - yz, g2, c0));
+                    const double z0 = q6.y, z1 = q7.x, z2 = q7.y;
+                    const double zv = dmin(dmin(z0, z1), z2) - 0x1p-40 * dmax(dmax(fabs(z0), fabs(z1)), fabs(z2));
+                    if (uxm > ma || uym > mb || usm < uz - (ma + mb) || vmax(zpl, zv) >= zmaxb) keep = false;
                 }
             }
             unsigned long long surv = __ballot(keep);
             TRGL_DBG(1, __popcll(surv));
             // ---- visits: the survivors in list order, constants through the scalar cache one visit ahead -------------------
+            // One visit = our_gl.cpp:147-152 for one triangle on this block, one pixel per lane, up to the coverage decision.
+            auto visit = [&](const TriScan& T, uint32_t tcur) {
+                double ux, uy;
+                unsigned long long cm;                    // lanes with a covered pixel that can still win the z-test (wave-uniform)
+#ifdef TRGL_DEBUG_COUNTERS
+                unsigned long long am = 0;
+#endif
+                const uint32_t ext = T.by - T.bx;         // (hi >= lo in both 16-bit halves: no borrow)
+                if (ALLWS || !(T.dl & TRGL_DL_LITERAL)) {
+                    // The core of a visit is written out instruction by instruction: 19 vector + 4 scalar instructions, straight-line
+                    // but for one branch.  (From C++ the compiler builds it with exec-mask regions: zero-initialised phi registers,
+                    // save / restore pairs and a mask -> vector -> mask round trip for the ballot: ~30 vector + ~25 scalar.)  Every
+                    // vector instruction issues for all 64 lanes whether they matter or not, so nothing is masked: lanes outside
+                    // (bbox n block), hidden lanes and uncovered lanes only drop out of the final mask.
+                    //   lanes of (bbox n block): x | y << 16 against the bbox as packed 16-bit words - both halves of (xy - lo) <= (hi - lo)
+                    //     (the subtraction of a half that lies below `lo` wraps to a large value)
+                    //   barycentric(), our_gl.cpp:77-86: s0z = ax - x, s1z = ay - y (s0.xy, s1.xy and u.z hoisted into the record)
+                    //   depth first: zpl = fma(s0z, g1, fma(s1z, g2, c0)); a pixel with zpl >= its stored depth fails the z-test whatever
+                    //     its coverage (k_setup); NaN reads as keep.  No lane left: the visit ends here.
+                    //   u.x = s0y s1z - s0z s1y (geometry.h:145), u.y = s0z s1x - s0x s1z (:146), us = u.x + u.y, every product and sum
+                    //     rounded on its own as in the reference
+                    //   covered <=> !(us < u.z) && !(u.y > 0) && !(u.x > 0): u.z < 0 and nothing can over/underflow, so the signs of the
+                    //     quotients of :85 are known without dividing ("exactness"); max(u.x, u.y) > 0 <=> one of them is.
+                    double s0z, s1z, ta, tb2;
+                    uint32_t tt;
+                    asm volatile(
+                        "v_pk_sub_i16 %[tt], %[xy], %[bx]\n\t"
+                        "v_add_f64 %[s0z], %[ax], -%[pxc]\n\t"
+                        "v_pk_max_u16 %[tt], %[tt], %[ext]\n\t"
+                        "v_add_f64 %[s1z], %[ay], -%[pyc]\n\t"
+                        "v_mov_b64 %[ta], %[c0]\n\t"
+                        "v_cmp_eq_u32_e64 %[cm], %[tt], %[ext]\n\t"
+#ifdef TRGL_DEBUG_COUNTERS
+                        "s_mov_b64 %[am], %[cm]\n\t"
+#endif
+                        "v_fmac_f64 %[ta], %[g2], %[s1z]\n\t"
+                        "v_fmac_f64 %[ta], %[g1], %[s0z]\n\t"
+                        "v_cmp_nge_f64_e32 vcc, %[ta], %[z]\n\t"
+                        "s_and_b64 %[cm], %[cm], vcc\n\t"
+                        "s_cbranch_scc0 .Lvisit_end%=\n\t"
+                        "v_mul_f64 %[ta], %[s0y], %[s1z]\n\t"
+                        "v_mul_f64 %[tb], %[s1y], %[s0z]\n\t"
+                        "v_add_f64 %[ux], %[ta], -%[tb]\n\t"
+                        "v_mul_f64 %[ta], %[s1x], %[s0z]\n\t"
+                        "v_mul_f64 %[tb], %[s0x], %[s1z]\n\t"
+                        "v_add_f64 %[uy], %[ta], -%[tb]\n\t"
+                        "v_add_f64 %[ta], %[ux], %[uy]\n\t"
+                        "v_max_f64 %[tb], %[ux], %[uy]\n\t"
+                        "v_cmp_nlt_f64_e64 vcc, %[ta], %[uz]\n\t"
+                        "s_and_b64 %[cm], %[cm], vcc\n\t"
+                        "v_cmp_nlt_f64_e32 vcc, 0, %[tb]\n\t"
+                        "s_and_b64 %[cm], %[cm], vcc\n"
+                        ".Lvisit_end%=:"
+                        : [cm] "=&s"(cm), [ux] "=&v"(ux), [uy] "=&v"(uy), [s0z] "=&v"(s0z), [s1z] "=&v"(s1z), [ta] "=&v"(ta), [tb] "=&v"(tb2), [tt] "=&v"(tt)
+#ifdef TRGL_DEBUG_COUNTERS
+                          , [am] "=&s"(am)
+#endif
+                        : [xy] "v"(S.xy), [pxc] "v"(S.pxc), [pyc] "v"(S.pyc), [z] "v"(S.z),
+                          [bx] "s"(T.bx), [ext] "s"(ext), [ax] "s"(T.ax), [ay] "s"(T.ay), [c0] "s"(T.c0), [g1] "s"(T.g1), [g2] "s"(T.g2),
+                          [s0x] "s"(T.s0x), [s0y] "s"(T.s0y), [s1x] "s"(T.s1x), [s1y] "s"(T.s1y), [uz] "s"(T.uz)
+                        : "vcc", "scc");
+                } else {
+                    // a triangle that is not well scaled: the same visit from C++, coverage from the literal quotients of :85
+                    const us2 off = S.xy - __builtin_bit_cast(us2, T.bx);
+                    const bool act = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(off, __builtin_bit_cast(us2, ext))) == ext;
+                    const double s0z = T.ax - S.pxc, s1z = T.ay - S.pyc;
+                    const double zpl = __builtin_fma(s0z, T.g1, __builtin_fma(s1z, T.g2, T.c0));
+                    ux = T.s0y * s1z - s0z * T.s1y;                               // geometry.h:145
+                    uy = s0z * T.s1x - T.s0x * s1z;                               // geometry.h:146
+                    const double us = ux + uy;
+                    const double b0 = 1.0 - us / T.uz, b1 = uy / T.uz, b2 = ux / T.uz;      // :85, as written
+                    cm = __ballot(act && !(zpl >= S.z) && !(b0 < 0 || b1 < 0 || b2 < 0));  // :152
+#ifdef TRGL_DEBUG_COUNTERS
+                    am = __ballot(act);
+#endif
+                }
+                const bool cov = __builtin_amdgcn_inverse_ballot_w64(cm);
+                TRGL_DBG(2, 1); TRGL_DBG(3, __popcll(am)); TRGL_DBG(4, cm ? 1 : 0); TRGL_DBG(5, __popcll(cm));
+                if (cm) {
+                    const unsigned long long both = cm & pend;
+                    if (both) {
+                        // Some covered lanes still hold a fragment of an earlier triangle, which has to be resolved first (submission
+                        // order per pixel).  Everything that can go goes in that one pass: the old fragments of all noted lanes AND the
+                        // new ones of the lanes that held none; only the conflicting lanes' new fragments stay noted afterwards.
+                        const bool held = __builtin_amdgcn_inverse_ballot_w64(pend);
+                        if (cov && !held) { S.pux = ux; S.puy = uy; S.ptri = tcur; }
+                        resolve<KIND, ALLWS, DEFERRED>(S, pend | cm, recs, recs_w, draws, stats, zero_locked);
+                        if (cov && held) { S.pux = ux; S.puy = uy; S.ptri = tcur; }
+                        pend = both;
+                    } else {
+                        if (cov) { S.pux = ux; S.puy = uy; S.ptri = tcur; }
+                        pend |= cm;
+                    }
+                }
+            };
             if (surv) {
-                uint32_t tcur = (uint32_t)__builtin_amdgcn_readlane((int)tri, __builtin_ctzll(surv));
-                TriScan T = load_scan(recs, tcur);
+                // Two sets of constants, A and B, take turns (no register copies): while a visit works on one, the request for
+                // the next survivor's record fills the other.  The wait for a set sits at the top of ITS visit, in front of the
+                // next request, so that inside a visit nothing is outstanding but that request.
+                uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)tri, __builtin_ctzll(surv)), tb;
+                TriScan A = load_scan(recs, ta), B;
+                asm volatile("" :: "s"(A.dl));       // the first triangle's constants are waited for HERE, not behind the first request inside the loop
                 for (;;) {
                     surv &= surv - 1;
-                    const uint32_t tnext = (uint32_t)__builtin_amdgcn_readlane((int)tri, surv ? __builtin_ctzll(surv) : 0);
-                    const TriScan N = load_scan(recs, tnext);
+                    tb = (uint32_t)__builtin_amdgcn_readlane((int)tri, surv ? __builtin_ctzll(surv) : 0);
+                    B = load_scan(recs, tb);
                     __builtin_amdgcn_sched_barrier(0);
-                    {
-                        // lanes of (bbox n block): scalar arithmetic, one 64-bit mask
-                        const int bx0 = (int)(T.bx & 0xffffu), by0 = (int)(T.bx >> 16), bx1 = (int)(T.by & 0xffffu), by1 = (int)(T.by >> 16);
-                        const unsigned long long rect = rect_mask(max(bx0 - X0, 0), max(by0 - Y0, 0), min(bx1 - X0, 7), min(by1 - Y0, 7));
-                        const bool act = __builtin_amdgcn_inverse_ballot_w64(rect);
-                        // barycentric(), our_gl.cpp:77-86 (s0.xy, s1.xy and u.z hoisted into the record)
-                        const double s0z = T.ax - S.pxc, s1z = T.ay - S.pyc;
-                        // depth first: a pixel whose plane value is not below its stored depth fails the z-test whatever its
-                        // coverage (k_setup); NaN reads as keep
-                        const double zpl = __builtin_fma(s0z, T.g1, __builtin_fma(s1z, T.g2, T.c0));
-                        const bool alive = act && !(zpl >= S.z);
-                        bool cov = false;
-                        double ux = 0.0, uy = 0.0;
-                        if (alive) {
-                            ux = T.s0y * s1z - s0z * T.s1y;                               // geometry.h:145
-                            uy = s0z * T.s1x - T.s0x * s1z;                               // geometry.h:146
-                            const double us = ux + uy;
-                            if (ALLWS || !(T.dl & TRGL_DL_LITERAL)) {
-                                // u.z < 0 and nothing can over/underflow, so the signs of the quotients are known without
-                                // dividing: u.y/u.z < 0 <=> u.y > 0, u.x/u.z < 0 <=> u.x > 0, and
-                                // 1 - RN(us/u.z) < 0 <=> RN(us/u.z) > 1 <=> us < u.z  ("exactness").
-                                cov = !(us < T.uz) && !(uy > 0.0) && !(ux > 0.0);         // :152
-                            } else {
-                                const double b0 = 1.0 - us / T.uz, b1 = uy / T.uz, b2 = ux / T.uz;      // :85, as written
-                                cov = !(b0 < 0 || b1 < 0 || b2 < 0);                      // :152
-                            }
-                        }
-                        const unsigned long long cm = __ballot(cov);
-                        TRGL_DBG(2, 1); TRGL_DBG(3, __popcll(rect)); TRGL_DBG(4, cm ? 1 : 0); TRGL_DBG(5, __popcll(cm));
-                        if (cm) {
-                            // a lane that still holds a fragment of an earlier triangle: resolve first (submission order per pixel)
-                            if (cm & pend) { resolve<KIND, ALLWS, DEFERRED>(S, pend, recs, recs_w, draws, stats, zero_locked); pend = 0; }
-                            if (cov) { S.pux = ux; S.puy = uy; S.ptri = tcur; }
-                            pend |= cm;
-                        }
-                    }
+                    visit(A, ta);
                     __builtin_amdgcn_sched_barrier(0);
                     if (!surv) break;
-                    T = N; tcur = tnext;
+                    asm volatile("" :: "s"(B.dl));
+                    surv &= surv - 1;
+                    ta = (uint32_t)__builtin_amdgcn_readlane((int)tri, surv ? __builtin_ctzll(surv) : 0);
+                    A = load_scan(recs, ta);
+                    __builtin_amdgcn_sched_barrier(0);
+                    visit(B, tb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!surv) break;
+                    asm volatile("" :: "s"(A.dl));
                 }
             }
         }
