@@ -387,20 +387,26 @@ __device__ __forceinline__ void resolve(BlockState& S, unsigned long long pend, 
                 }
             }
             if (!discard) {
-                S.z = z;                                                    // :191
-                if (DEFERRED) S.id = id;
-                if (!DEFERRED || id == 0xffffffffu) S.color = color;        // :192 (tgaimage.cpp:32-39 at tile-out)
-                ++S.frags;                                                  // :194
+                // :191-198, committed IN PLACE (asm operands tied to the state registers): written through ordinary assignments the
+                // compiler gives every state variable a second register inside the conditional resolve and copies all of them back at
+                // its end - nine moves per covered visit.  v_min / v_max give std::min / std::max up to the sign of a zero, which
+                // k_fold_stats settles from the first-zero keys below.
+                const uint32_t ncol = (!DEFERRED || id == 0xffffffffu) ? color : S.color;       // :192 (tgaimage.cpp:32-39 at block-out)
+                asm volatile(
+                    "v_mov_b64 %[sz], %[z]\n\t"                                                // :191
+                    "v_mov_b32 %[sc], %[nc]\n\t"
+                    "v_add_u32 %[fr], 1, %[fr]\n\t"                                            // :194
+                    "v_min_f64 %[zmin], %[zmin], %[z]\n\t"                                     // :197
+                    "v_max_f64 %[zmax], %[zmax], %[z]"                                           // :198
+                    : [sz] "+v"(S.z), [sc] "+v"(S.color), [fr] "+v"(S.frags), [zmin] "+v"(S.zmin), [zmax] "+v"(S.zmax)
+                    : [z] "v"(z), [nc] "v"(ncol));
+                if (DEFERRED) asm volatile("v_mov_b32 %0, %1" : "+v"(S.id) : "v"(id));
                 TRGL_DBG(8, 1);
-                // :197-198.  After a few fragments a lane's running min/max rarely moves, so the updates live in a branch.  A
-                // written zero can only end up as a z-range end if it is a new min or max of its lane when it is written, so the
-                // first-zero bookkeeping lives there too.
-                if ((z < S.zmin) || (S.zmax < z)) {
-                    S.zmin = dmin(S.zmin, z); S.zmax = dmax(S.zmax, z);
-                    if (z == 0.0 && !zero_locked) {
-                        unsigned long long order = ((unsigned long long)S.ptri << 32) | ((unsigned long long)S.x << 16) | (unsigned long long)S.y;
-                        atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
-                    }
+                // std::min / std::max keep the first of equal values and +0.0 == -0.0: when the z range ends in a zero its sign is that
+                // of the first zero written in the reference's order (triangle, x, y), see DevStats
+                if (z == 0.0 && !zero_locked) {
+                    unsigned long long order = ((unsigned long long)S.ptri << 32) | ((unsigned long long)S.x << 16) | (unsigned long long)S.y;
+                    atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
                 }
             }
         }
@@ -606,8 +612,17 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
             // ---- visits: the survivors in list order, constants through the scalar cache one visit ahead -------------------
             // One visit = our_gl.cpp:147-152 for one triangle on this block, one pixel per lane, up to the coverage decision.
             auto visit = [&](const TriScan& T, uint32_t tcur) {
+                // the lanes of `m` note (u.x, u.y, triangle): moves under the mask, in place
+                auto note = [&](unsigned long long m, double ux, double uy) {
+                    unsigned long long sv;
+                    asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\tv_mov_b64 %[px], %[ux]\n\tv_mov_b64 %[py], %[uy]\n\t"
+                                 "v_mov_b32 %[pt], %[t]\n\ts_mov_b64 exec, %[sv]"
+                                 : [px] "+v"(S.pux), [py] "+v"(S.puy), [pt] "+v"(S.ptri), [sv] "=&s"(sv)
+                                 : [ux] "v"(ux), [uy] "v"(uy), [t] "s"(tcur), [m] "s"(m));
+                };
                 double ux, uy;
                 unsigned long long cm;                    // lanes with a covered pixel that can still win the z-test (wave-uniform)
+                unsigned long long both, sv, sx;          // ... that still hold a fragment of an earlier triangle; scratch
 #ifdef TRGL_DEBUG_COUNTERS
                 unsigned long long am = 0;
 #endif
@@ -655,13 +670,30 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                         "v_cmp_nlt_f64_e64 vcc, %[ta], %[uz]\n\t"
                         "s_and_b64 %[cm], %[cm], vcc\n\t"
                         "v_cmp_nlt_f64_e32 vcc, 0, %[tb]\n\t"
-                        "s_and_b64 %[cm], %[cm], vcc\n"
-                        ".Lvisit_end%=:"
-                        : [cm] "=&s"(cm), [ux] "=&v"(ux), [uy] "=&v"(uy), [s0z] "=&v"(s0z), [s1z] "=&v"(s1z), [ta] "=&v"(ta), [tb] "=&v"(tb2), [tt] "=&v"(tt)
+                        "s_and_b64 %[cm], %[cm], vcc\n\t"
+                        "s_cbranch_scc0 .Lvisit_end%=\n\t"
+                        // covered lanes: those that hold no fragment note (u.x, u.y, triangle) at once, in place (moves under the mask);
+                        // `both` = the covered lanes that still hold one (the caller resolves first, then notes theirs)
+                        "s_and_b64 %[both], %[cm], %[pend]\n\t"
+                        "s_or_b64 %[pend], %[pend], %[cm]\n\t"
+                        "s_xor_b64 %[sv], %[cm], %[both]\n\t"
+                        "s_cbranch_scc0 .Lvisit_done%=\n\t"
+                        "s_mov_b64 %[sx], exec\n\t"
+                        "s_mov_b64 exec, %[sv]\n\t"
+                        "v_mov_b64 %[pux], %[ux]\n\t"
+                        "v_mov_b64 %[puy], %[uy]\n\t"
+                        "v_mov_b32 %[ptri], %[tcur]\n\t"
+                        "s_mov_b64 exec, %[sx]\n\t"
+                        "s_branch .Lvisit_done%=\n"
+                        ".Lvisit_end%=:\n\t"
+                        "s_mov_b64 %[both], 0\n"
+                        ".Lvisit_done%=:"
+                        : [cm] "=&s"(cm), [ux] "=&v"(ux), [uy] "=&v"(uy), [s0z] "=&v"(s0z), [s1z] "=&v"(s1z), [ta] "=&v"(ta), [tb] "=&v"(tb2), [tt] "=&v"(tt),
+                          [both] "=&s"(both), [sv] "=&s"(sv), [sx] "=&s"(sx), [pend] "+s"(pend), [pux] "+v"(S.pux), [puy] "+v"(S.puy), [ptri] "+v"(S.ptri)
 #ifdef TRGL_DEBUG_COUNTERS
                           , [am] "=&s"(am)
 #endif
-                        : [xy] "v"(S.xy), [pxc] "v"(S.pxc), [pyc] "v"(S.pyc), [z] "v"(S.z),
+                        : [xy] "v"(S.xy), [pxc] "v"(S.pxc), [pyc] "v"(S.pyc), [z] "v"(S.z), [tcur] "s"(tcur),
                           [bx] "s"(T.bx), [ext] "s"(ext), [ax] "s"(T.ax), [ay] "s"(T.ay), [c0] "s"(T.c0), [g1] "s"(T.g1), [g2] "s"(T.g2),
                           [s0x] "s"(T.s0x), [s0y] "s"(T.s0y), [s1x] "s"(T.s1x), [s1y] "s"(T.s1y), [uz] "s"(T.uz)
                         : "vcc", "scc");
@@ -679,24 +711,19 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
 #ifdef TRGL_DEBUG_COUNTERS
                     am = __ballot(act);
 #endif
+                    both = cm & pend;
+                    note(cm & ~pend, ux, uy);
+                    pend |= cm;
                 }
-                const bool cov = __builtin_amdgcn_inverse_ballot_w64(cm);
                 TRGL_DBG(2, 1); TRGL_DBG(3, __popcll(am)); TRGL_DBG(4, cm ? 1 : 0); TRGL_DBG(5, __popcll(cm));
-                if (cm) {
-                    const unsigned long long both = cm & pend;
-                    if (both) {
-                        // Some covered lanes still hold a fragment of an earlier triangle, which has to be resolved first (submission
-                        // order per pixel).  Everything that can go goes in that one pass: the old fragments of all noted lanes AND the
-                        // new ones of the lanes that held none; only the conflicting lanes' new fragments stay noted afterwards.
-                        const bool held = __builtin_amdgcn_inverse_ballot_w64(pend);
-                        if (cov && !held) { S.pux = ux; S.puy = uy; S.ptri = tcur; }
-                        resolve<KIND, ALLWS, DEFERRED>(S, pend | cm, recs, recs_w, draws, stats, zero_locked);
-                        if (cov && held) { S.pux = ux; S.puy = uy; S.ptri = tcur; }
-                        pend = both;
-                    } else {
-                        if (cov) { S.pux = ux; S.puy = uy; S.ptri = tcur; }
-                        pend |= cm;
-                    }
+                if (both) {
+                    // Some covered lanes still hold a fragment of an earlier triangle, which has to be resolved first (submission
+                    // order per pixel).  Everything that can go goes in that one pass: the old fragments of all noted lanes AND the
+                    // new ones of the lanes that held none (`pend` holds them already); only the conflicting lanes' new fragments
+                    // stay noted afterwards.
+                    resolve<KIND, ALLWS, DEFERRED>(S, pend, recs, recs_w, draws, stats, zero_locked);
+                    note(both, ux, uy);
+                    pend = both;
                 }
             };
             if (surv) {
