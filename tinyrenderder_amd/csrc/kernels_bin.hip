@@ -134,8 +134,8 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
             // Depth plane of the early depth test (k_raster).  The z of our_gl.cpp:156-158 is the plane
             //   z0 + ((ax - x) Gx + (ay - y) Gy) / u.z,  Gx = s1x (z1-z0) - s1y (z2-z0),  Gy = s0y (z2-z0) - s0x (z1-z0)
             // through the three vertices up to the roundings of u.x, u.y, the three quotients and the weighted sum: at most
-            // 2^-50 max|z_i| (R S / |u.z| + 1) for a covered pixel, where R >= |A - pixel centre| (L1) over the clamped bbox and
-            // S = the sum of the |edge deltas|.  g1 = Gx/u.z and g2 = Gy/u.z carry a few more roundings of that size, so does the
+            // 2^-50 max|z_i| (R S / |u.z| + 1) for a covered pixel, where R >= |A - pixel centre| (L1) over the clamped bbox (and R >= S)
+            // and S = the sum of the |edge deltas|.  g1 = Gx/u.z and g2 = Gy/u.z carry a few more roundings of that size, so does the
             // evaluation c0 + (ax - x) g1 + (ay - y) g2 itself, and c0 = z0 - 2^-39 max|z_i| (R S / |u.z| + 1) covers all of it a
             // thousand times over: a pixel whose plane value is >= the stored depth fails the strict `<` of :165 whatever its
             // coverage and low bits.  Switched off (c0 = -inf, g = 0) for triangles that are not well scaled and when a constant
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
                 const double h1 = (r.s1x * dz1 - r.s1y * dz2) * r.ruz, h2 = (r.s0y * dz2 - r.s0x * dz1) * r.ruz;
                 const double rx = fmax(fabs(r.ax - ((double)bx0 + 0.5)), fabs(r.ax - ((double)bx1 + 0.5)));
                 const double ry = fmax(fabs(r.ay - ((double)by0 + 0.5)), fabs(r.ay - ((double)by1 + 0.5)));
-                const double R = rx + ry + 1.0;
                 const double Ssum = (fabs(r.s0x) + fabs(r.s0y)) + (fabs(r.s1x) + fabs(r.s1y));
+                const double R = rx + ry + 1.0 + Ssum;       // (+ S: the plane is also evaluated at the three vertices, k_raster's cull)
                 const double mz = zabs * 0x1p-39 * (R * Ssum * fabs(r.ruz) + 1.0) + 0x1p-600;
                 // trusted only while nothing can overflow (R |g| bounds each product of the test); NaN compares false
                 const bool okp = zabs < 0x1p1000 && R * fabs(h1) < 0x1p900 && R * fabs(h2) < 0x1p900 && mz < 0x1p1000;

@@ -288,7 +288,7 @@ __device__ __forceinline__ double div_by_uz(double a, double uz, double ruz) {
 // well-scaled triangles ("exactness"), the literal divisions for the others (`dl` bit 31).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int KIND_ANY = TRGL_NUM_SHADERS;          // per-fragment switch on the draw's kind (mixed flushes)
-constexpr int RING = 128;                           // candidate ring of a wave (triangle ids), a power of two >= 2 * 64
+constexpr int RING = 512;                           // candidate ring of a wave (triangle ids): a power of two >= 63 left over + 256 of a step
 
 #ifdef TRGL_DEBUG_COUNTERS
 #define TRGL_DBG(i, n) do { S.dbg[i] += (unsigned long long)(n); } while (0)
@@ -307,6 +307,9 @@ struct TriScan {
 };
 __device__ __forceinline__ TriScan load_scan(const TriRec* __restrict__ recs, uint32_t tri) {
     TriScan T;
+#ifdef TRGL_EXP_SAMEREC
+    tri &= 63u;          // timing experiment only (wrong frames): every visit reads one of 64 records = scalar-cache hits
+#endif
 #if __HIP_DEVICE_COMPILE__
     CRec* r = (CRec*)(recs + tri);
     T.ax = r->ax; T.ay = r->ay; T.s0x = r->s0x; T.s0y = r->s0y; T.s1x = r->s1x; T.s1y = r->s1y; T.c0 = r->c0; T.uz = r->uz;
@@ -468,12 +471,15 @@ __device__ __forceinline__ void clear_rows(const FrameParams& fp, int lane, int 
 // Work items (k_make_items): one per workgroup.
 //   bits 0-23 tile, bits 24-25 row of blocks inside the tile, bit 31: the tile has no triangles and is only cleared
 #define TRGL_ITEM_CLEAR 0x80000000u
+#ifndef TRGL_RASTER_WAVES
+#define TRGL_RASTER_WAVES 6        // waves per SIMD the register allocation of k_raster aims at (80 vector registers)
+#endif
 
 // BPP: the framebuffer's bytes per pixel when the kernel is compiled for one (3 or 4, FLAT only), 0 = read from FrameParams
 // ALLWS: the flush holds no triangle that needs the literal path (k_setup counted them): the kernel is compiled without it
 // DEFERRED: the flush has PHONG / EYE draws (visibility buffer + k_shade)
 template <int KIND, int BPP = 0, bool ALLWS = false>
-__global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __restrict__ recs, const TriW* __restrict__ recs_w,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER_WAVES, 8))) void k_raster(FrameParams fp, const TriRec* __restrict__ recs, const TriW* __restrict__ recs_w,
                                                 const uint32_t* __restrict__ vals, const uint16_t* __restrict__ bmask,
                                                 const uint32_t* __restrict__ tile_start,
                                                 const uint32_t* __restrict__ tile_end,
@@ -483,6 +489,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
     constexpr bool DEFERRED = KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE || KIND == KIND_ANY;
     __shared__ uint32_t s_ring[4][RING];
     __shared__ uint32_t s_out[4][64];
+    __shared__ unsigned long long s_part[4][3];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): workgroup b runs on the XCD of b mod 8.  Give every
@@ -491,17 +498,17 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
     const uint32_t G = n_items[0];
     const uint32_t per = (G + 7u) >> 3, xj = blockIdx.x >> 3;
     const uint32_t g = (blockIdx.x & 7u) * per + xj;
-    if (xj >= per || g >= G) return;                      // (no block-level barrier is used below)
+    if (xj >= per || g >= G) return;                      // (block-uniform, like the clear-only exit below: the one barrier at the end is safe)
     const uint32_t item = items[g];
     const int t = (int)(item & 0xffffffu);
     const int tile_y = t / fp.tiles_x, tile_x = t - tile_y * fp.tiles_x;
     const int px0 = tile_x << TRGL_TILE_LOG2, py0 = tile_y << TRGL_TILE_LOG2;
-    unsigned long long* my_stats = item_stats + ((size_t)g * 4 + w) * 4;
+    unsigned long long* my_stats = item_stats + (size_t)g * 4;
     if (item & TRGL_ITEM_CLEAR) {                         // cleared and empty: store the clear values, nothing else
         // rows [py0 + 8 w, py0 + 8 w + 7] of the tile for wave w
         const int ya = max(py0 + 8 * w, fp.strip_y0), yb = min(min(py0 + 8 * w + 7, fp.H - 1), fp.strip_y1 - 1);
         if (ya <= yb) clear_rows(fp, lane, px0, ya, yb);
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             ulonglong2* dst = reinterpret_cast<ulonglong2*>(my_stats);
             dst[0] = make_ulonglong2(0ull, ~0ull); dst[1] = make_ulonglong2(0ull, 0ull);
         }
@@ -534,30 +541,48 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
     const uint32_t beg = tile_start[t], end = tile_end[t];
     uint32_t* ring = s_ring[w];
     uint32_t head = 0, cnt = 0;                           // ring: `cnt` candidates wait from position `head` on
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
-    // the list, 64 entries per step; the entries of the next step are requested before the candidates of this one are processed
-    // (loads without a branch around them - clamped index, mask cleared past the end - so that the wait for THIS step's entries can
-    // leave the next step's loads in flight)
-    uint32_t tri_n = 0, msk_n = 0;
-    if (beg < end) {
-        const uint32_t p = min(beg + lane, end - 1);
-        tri_n = vals[p]; msk_n = (beg + lane < end) ? bmask[p] : 0u;
-    }
-    for (uint32_t p0 = beg; p0 < end; p0 += 64) {
-        const uint32_t tri_c = tri_n, msk_c = msk_n;
+    // The list, 256 entries per step: lane l takes entries 4 l .. 4 l + 3 of the step (one 16-byte load of triangle ids, one 8-byte
+    // load of block masks; steps start at a multiple of 4 entries, the pair buffers hold a multiple of 4).  The entries of the next
+    // step are requested before the candidates of this one are processed.  Loads without a branch around them (clamped index, masks
+    // cleared outside [beg, end)), so that the wait for THIS step's entries can leave the next step's loads in flight.
+    const uint32_t p_first = beg & ~3u;
+    auto load_step = [&](uint32_t p0, uint4& tri4, uint32_t& cand4) {
+        const uint32_t pl = p0 + 4u * (uint32_t)lane, p = min(pl, (end - 1u) & ~3u);
+        tri4 = *reinterpret_cast<const uint4*>(vals + p);
+        const uint2 m = *reinterpret_cast<const uint2*>(bmask + p);
+        // bit j: entry pl + j is in [beg, end) and its bbox reaches this wave's block
+        uint32_t c = ((m.x >> kblk) & 1u) | (((m.x >> (16 + kblk)) & 1u) << 1) | (((m.y >> kblk) & 1u) << 2) | (((m.y >> (16 + kblk)) & 1u) << 3);
+        const uint32_t lo = pl < beg ? min(beg - pl, 4u) : 0u, hi = pl < end ? min(end - pl, 4u) : 0u;   // valid entries of the lane: [lo, hi)
+        c &= (0xfu << lo) & (0xfu >> (4u - hi));
+        cand4 = c;
+    };
+    uint4 tri_n = make_uint4(0, 0, 0, 0); uint32_t cand_n = 0;
+    if (beg < end) load_step(p_first, tri_n, cand_n);
+    for (uint32_t p0 = p_first; p0 < end; p0 += 256) {
+        const uint4 tri_c = tri_n; const uint32_t cand_c = cand_n;
+        load_step(p0 + 256, tri_n, cand_n);               // (past the end: clamped index, no candidates)
+        // append the step's candidates to the ring in list order: entry 4 l + j comes after every entry of the lanes below l
         {
-            const uint32_t pn = p0 + 64 + lane, p = min(pn, end - 1);
-            tri_n = vals[p]; msk_n = bmask[p];
-            if (pn >= end) msk_n = 0;
+            const unsigned long long b0 = __ballot(cand_c & 1u), b1 = __ballot(cand_c & 2u), b2 = __ballot(cand_c & 4u), b3 = __ballot(cand_c & 8u);
+            if (b0 | b1 | b2 | b3) {
+                uint32_t pos = head + cnt;
+                pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u));
+                pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+                pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+                pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, 0u));
+                if (cand_c & 1u) ring[pos & (RING - 1)] = tri_c.x;
+                pos += cand_c & 1u;
+                if (cand_c & 2u) ring[pos & (RING - 1)] = tri_c.y;
+                pos += (cand_c >> 1) & 1u;
+                if (cand_c & 4u) ring[pos & (RING - 1)] = tri_c.z;
+                pos += (cand_c >> 2) & 1u;
+                if (cand_c & 8u) ring[pos & (RING - 1)] = tri_c.w;
+                const uint32_t added = (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+                cnt += added;
+                TRGL_DBG(0, added);
+            }
         }
-        const bool cand = (msk_c >> kblk) & 1u;           // (entries past the end carry an empty mask)
-        const unsigned long long cb = __ballot(cand);
-        if (cb) {
-            if (cand) ring[(head + cnt + (uint32_t)__popcll(cb & lanes_below)) & (RING - 1)] = tri_c;
-            cnt += (uint32_t)__popcll(cb);
-        }
-        TRGL_DBG(0, __popcll(cb));
-        const bool last = p0 + 64 >= end;
+        const bool last = p0 + 256 >= end;
         while (cnt >= 64 || (last && cnt)) {
             const uint32_t n = cnt < 64 ? cnt : 64;
             __builtin_amdgcn_wave_barrier();
@@ -572,7 +597,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
             bool keep = (uint32_t)lane < n;
             if (keep) {
                 const double2* q = reinterpret_cast<const double2*>(recs + tri);
-                const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q6 = q[6], q7 = q[7];
+                const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
                 const uint4 q5 = reinterpret_cast<const uint4*>(q)[5];
                 if (ALLWS || !(q5.w & TRGL_DL_LITERAL)) {
                     const double ax = q0.x, ay = q0.y, s0x = q1.x, s0y = q1.y, s1x = q2.x, s1y = q2.y, c0 = q3.x, uz = q3.y, g1 = q4.x, g2 = q4.y;
@@ -599,11 +624,13 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
                     // over the rectangle again sits at a corner; if even that is not below the block's largest stored depth,
                     // no pixel of the block passes the strict `<` of :165.  NaN compares false = keep.
                     // The plane reaches below the triangle's own depths outside the triangle; a covered pixel also has b_i >= 0 and
-                    // b0 + b1 + b2 = 1 +- 2^-50, hence z >= min(z0, z1, z2) - 2^-40 max|z_i|: the larger of the two bounds counts.
+                    // b0 + b1 + b2 = 1 +- 2^-50, hence z >= min(z0, z1, z2) - 2^-40 max|z_i|, and the plane's values AT the three vertices
+                    // A, A + (s0y, s1y), A + (s0x, s1x) are z_i minus k_setup's margin (>= 2^-39 max|z_i| (R S/|u.z| + 1) with R >= S, which
+                    // also covers the roundings of these three evaluations): their minimum is below that bound.  The larger of the two
+                    // lower bounds counts.
                     const double xz = g1 >= 0.0 ? xhi : xlo, yz = g2 >= 0.0 ? yhi : ylo;
                     const double zpl = __builtin_fma(ax - xz, g1, __builtin_fma(ay - yz, g2, c0));
-                    const double z0 = q6.y, z1 = q7.x, z2 = q7.y;
-                    const double zv = dmin(dmin(z0, z1), z2) - 0x1p-40 * dmax(dmax(fabs(z0), fabs(z1)), fabs(z2));
+                    const double zv = dmin(dmin(c0, __builtin_fma(-s0y, g1, __builtin_fma(-s1y, g2, c0))), __builtin_fma(-s0x, g1, __builtin_fma(-s1x, g2, c0)));
                     if (uxm > ma || uym > mb || usm < uz - (ma + mb) || vmax(zpl, zv) >= zmaxb) keep = false;
                 }
             }
@@ -792,7 +819,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
         }
     }
 
-    // ---- stats: our_gl.cpp:194-198, reduced per wave, one partial per wave (k_fold_stats) ------------------------------
+    // ---- stats: our_gl.cpp:194-198, reduced per wave, then per workgroup: one partial per work item (k_fold_stats) ------
     uint32_t frags = S.frags;
     unsigned long long kmin = zkey(S.zmin), kmax = zkey(S.zmax);
     for (int o = 32; o; o >>= 1) {
@@ -804,10 +831,14 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const TriRec* __
     for (int o = 32; o; o >>= 1) S.dbg[8] += __shfl_xor(S.dbg[8], o);
     if (lane == 0) for (int k = 0; k < 16; ++k) if (S.dbg[k]) atomicAdd(&stats->dbg[k], S.dbg[k]);
 #endif
-    if (lane == 0) {
+    if (lane == 0) { s_part[w][0] = frags; s_part[w][1] = kmin; s_part[w][2] = kmax; }
+    __syncthreads();                 // the only block-level barrier of the kernel, when every wave of the workgroup is done
+    if (threadIdx.x == 0) {
+        unsigned long long f = 0, mn = ~0ull, mx = 0ull;
+        for (int k = 0; k < 4; ++k) { f += s_part[k][0]; mn = s_part[k][1] < mn ? s_part[k][1] : mn; mx = s_part[k][2] > mx ? s_part[k][2] : mx; }
         ulonglong2* dst = reinterpret_cast<ulonglong2*>(my_stats);
-        dst[0] = make_ulonglong2((unsigned long long)frags, kmin);
-        dst[1] = make_ulonglong2(kmax, 0ull);
+        dst[0] = make_ulonglong2(f, mn);
+        dst[1] = make_ulonglong2(mx, 0ull);
     }
 }
 
@@ -985,12 +1016,12 @@ __global__ __launch_bounds__(256) void k_make_items(FrameParams fp, const uint32
     else for (uint32_t r = 0; r < 4; ++r) if ((rows >> r) & 1u) items[base++] = t | (r << 24);
 }
 
-// after the raster kernel of a flush: fold the per-wave partials (four per work item) into the context's counters
+// after the raster kernel of a flush: fold the per-item partials into the context's counters
 // (our_gl.cpp:194-198) and fix the sign of a zero z-range end (see DevStats).  One block.
 __global__ __launch_bounds__(1024) void k_fold_stats(DevStats* __restrict__ s, uint32_t* __restrict__ n_items,
                                                      const unsigned long long* __restrict__ item_stats) {
     __shared__ unsigned long long sh[3][16];
-    const uint32_t n = *n_items * 4u;
+    const uint32_t n = *n_items;
     unsigned long long fr = 0, kmin = ~0ull, kmax = 0ull;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         const ulonglong2 a = reinterpret_cast<const ulonglong2*>(item_stats + (size_t)i * 4)[0];

@@ -30,7 +30,7 @@ void launch_bounds(hipStream_t s, const void* keys, bool key16, const unsigned l
 
 uint32_t owned_tiles(const FrameParams& fp);       // tiles of the rows this context owns (strip or interleaved bands)
 uint32_t raster_max_items(const FrameParams& fp);   // work items (workgroups of k_raster) of a flush, at most
-// item_stats: 16 x uint64 per work item (one partial of the counters per wave)
+// item_stats: 4 x uint64 per work item (one partial of the counters per workgroup)
 void launch_raster(hipStream_t s, const FrameParams& fp, int kind, bool all_well_scaled, const TriRec* recs, const TriW* recs_w,
                    const uint32_t* vals, const uint16_t* bmask,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,

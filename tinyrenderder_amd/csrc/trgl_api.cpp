@@ -591,7 +591,7 @@ int trgl_flush_end(trgl_ctx* c) {
     // one work item (a workgroup of four block waves) per row of blocks of every owned tile
     const uint32_t max_items = raster_max_items(fp);
     if ((r = grow(c, c->items, c->cap_items, (size_t)max_items + 64))) return r;
-    if ((r = grow(c, c->item_stats, c->cap_item_stats, ((size_t)max_items + 64) * 16))) return r;
+    if ((r = grow(c, c->item_stats, c->cap_item_stats, ((size_t)max_items + 64) * 4))) return r;
     // k_setup counted the triangles that are not well scaled (it came over with the pair count): without any, the kernel without the literal path
     const bool all_well_scaled = N == 0 || c->stats_pinned->literal_tris == 0;
     launch_raster(s, fp, flush_kind, all_well_scaled, recs_arg, c->recs_w, vals_arg, bmask_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev,
