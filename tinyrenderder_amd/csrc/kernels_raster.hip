@@ -292,8 +292,11 @@ constexpr int RING = 512;                           // candidate ring of a wave 
 
 #ifdef TRGL_DEBUG_COUNTERS
 #define TRGL_DBG(i, n) do { S.dbg[i] += (unsigned long long)(n); } while (0)
+// phase clocks of the diagnostic build: the cycles since the last stamp go to counter i
+#define TRGL_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); S.dbg[i] += t_ - S.t_prev; S.t_prev = t_; } while (0)
 #else
 #define TRGL_DBG(i, n) ((void)0)
+#define TRGL_STAMP(i) ((void)0)
 #endif
 
 typedef const __attribute__((address_space(4))) TriRec CRec;      // records through the scalar cache
@@ -302,8 +305,9 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 // The scan constants of one triangle, wave-uniform (SGPRs): chunks 0-5 of its record.
 struct TriScan {
     double ax, ay, s0x, s0y, s1x, s1y, c0, uz, g1, g2;
-    uint32_t bx, by;      // bx0 | bx1 << 16 ... as stored: bx0, by0 | bx1, by1
+    uint32_t bx, by;      // as stored: bx0 | by0 << 16, bx1 | by1 << 16
     uint32_t color, dl;
+    double ruz, z0, z1, z2;       // ride along for the lanes that note a fragment (see BlockState)
 };
 __device__ __forceinline__ TriScan load_scan(const TriRec* __restrict__ recs, uint32_t tri) {
     TriScan T;
@@ -316,6 +320,7 @@ __device__ __forceinline__ TriScan load_scan(const TriRec* __restrict__ recs, ui
     T.g1 = r->g1; T.g2 = r->g2;
     const __attribute__((address_space(4))) uint32_t* q = (const __attribute__((address_space(4))) uint32_t*)r + 20;
     T.bx = q[0]; T.by = q[1]; T.color = q[2]; T.dl = q[3];
+    T.ruz = r->ruz; T.z0 = r->z0; T.z1 = r->z1; T.z2 = r->z2;
 #endif
     return T;
 }
@@ -326,13 +331,18 @@ struct BlockState {
     uint32_t color;         // its colour, b | g << 8 | r << 16 | a << 24
     uint32_t id;            // PHONG / EYE flushes: draw << 24 | triangle of the fragment that owns the pixel, ~0u = none (k_shade)
     double pxc, pyc;        // pixel centre (x + 0.5, y + 0.5), our_gl.cpp:149
-    // deferred fragments: lanes of `pend` hold (u.x, u.y) of barycentric() and their triangle; resolved by resolve()
+    // deferred fragments: lanes of `pend` hold (u.x, u.y) of barycentric(), their triangle and - copied from the wave-uniform
+    // constants of the visit, so that resolving them needs no memory access at all - its u.z, 1/u.z and the three vertex depths
     double pux, puy; uint32_t ptri;
+    double puz, pruz, pz0, pz1, pz2;
+    uint32_t wtri;          // FLAT / PHONG / EYE flushes: the triangle of the fragment that owns the pixel (its colour / owner id is fetched
+                            // once, at block-out), ~0u = none written in this flush
     uint32_t frags; double zmin, zmax;
     int x, y;
     us2 xy;                 // x | y << 16 as two 16-bit words (the bbox test of a visit is packed 16-bit arithmetic)
 #ifdef TRGL_DEBUG_COUNTERS
     unsigned long long dbg[16];    // work counters of the diagnostic build (profiles/raster_counters.py); [8] is summed over the lanes
+    unsigned long long t_prev;
 #endif
 };
 
@@ -342,13 +352,14 @@ template <int KIND, bool ALLWS, bool DEFERRED>
 __device__ __forceinline__ void resolve(BlockState& S, unsigned long long pend, const TriRec* __restrict__ recs, const TriW* __restrict__ recs_w,
                                         const DrawDesc* __restrict__ draws, DevStats* __restrict__ stats, bool zero_locked) {
     TRGL_DBG(6, 1); TRGL_DBG(7, __popcll(pend));
+#ifdef TRGL_DEBUG_COUNTERS
+    const unsigned long long t_res = __builtin_amdgcn_s_memtime();
+#endif
+    // LATE: every fragment of the flush is FLAT, PHONG or EYE: its colour / owner id depends on the triangle only, so the lane just
+    // remembers the winning triangle and block-out fetches colour or id once per pixel; resolving then touches no memory at all.
+    constexpr bool LATE = KIND == TRGL_SHADER_FLAT || KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE;
     if (__builtin_amdgcn_inverse_ballot_w64(pend)) {
-        const TriRec* r = recs + S.ptri;
-        const double uz = r->uz;
-        const double2 c6 = *reinterpret_cast<const double2*>(&r->ruz);      // ruz, z0
-        const double2 c7 = *reinterpret_cast<const double2*>(&r->z1);       // z1, z2
-        const uint2 cd = *reinterpret_cast<const uint2*>(&r->color);        // color, dl
-        const double ruz = c6.x, z0 = c6.y, z1 = c7.x, z2 = c7.y;
+        const double uz = S.puz, ruz = S.pruz, z0 = S.pz0, z1 = S.pz1, z2 = S.pz2;
         const double ux = S.pux, uy = S.puy, us = ux + uy;
         double b0, b1, b2;
         if (ALLWS || ruz != 0.0) {
@@ -362,11 +373,12 @@ __device__ __forceinline__ void resolve(BlockState& S, unsigned long long pend, 
         }
         const double z = b0 * z0 + b1 * z1 + b2 * z2;                       // :156-158
         if (__builtin_isfinite(z) && (z < S.z)) {                           // :160, :165
-            const uint32_t dl = cd.y;
-            uint32_t color = cd.x;
-            uint32_t id = 0xffffffffu;
+            uint32_t color = 0, id = 0xffffffffu;
             bool discard = false;
-            if (KIND != TRGL_SHADER_FLAT) {
+            if (!LATE) {
+                const uint2 cd = *reinterpret_cast<const uint2*>(&recs[S.ptri].color);        // color, dl
+                const uint32_t dl = cd.y;
+                color = cd.x;
                 const DrawDesc* d = draws + TRGL_DL_DRAW(dl);
                 const int kind = KIND == KIND_ANY ? d->kind : KIND;
                 if (kind == TRGL_SHADER_PHONG || kind == TRGL_SHADER_EYE) {
@@ -394,16 +406,20 @@ __device__ __forceinline__ void resolve(BlockState& S, unsigned long long pend, 
                 // compiler gives every state variable a second register inside the conditional resolve and copies all of them back at
                 // its end - nine moves per covered visit.  v_min / v_max give std::min / std::max up to the sign of a zero, which
                 // k_fold_stats settles from the first-zero keys below.
-                const uint32_t ncol = (!DEFERRED || id == 0xffffffffu) ? color : S.color;       // :192 (tgaimage.cpp:32-39 at block-out)
                 asm volatile(
                     "v_mov_b64 %[sz], %[z]\n\t"                                                // :191
-                    "v_mov_b32 %[sc], %[nc]\n\t"
                     "v_add_u32 %[fr], 1, %[fr]\n\t"                                            // :194
                     "v_min_f64 %[zmin], %[zmin], %[z]\n\t"                                     // :197
                     "v_max_f64 %[zmax], %[zmax], %[z]"                                           // :198
-                    : [sz] "+v"(S.z), [sc] "+v"(S.color), [fr] "+v"(S.frags), [zmin] "+v"(S.zmin), [zmax] "+v"(S.zmax)
-                    : [z] "v"(z), [nc] "v"(ncol));
-                if (DEFERRED) asm volatile("v_mov_b32 %0, %1" : "+v"(S.id) : "v"(id));
+                    : [sz] "+v"(S.z), [fr] "+v"(S.frags), [zmin] "+v"(S.zmin), [zmax] "+v"(S.zmax)
+                    : [z] "v"(z));
+                if (LATE) {
+                    asm volatile("v_mov_b32 %0, %1" : "+v"(S.wtri) : "v"(S.ptri));              // :192 (colour / owner at block-out)
+                } else {
+                    const uint32_t ncol = (!DEFERRED || id == 0xffffffffu) ? color : S.color;   // :192 (tgaimage.cpp:32-39 at block-out)
+                    asm volatile("v_mov_b32 %0, %1" : "+v"(S.color) : "v"(ncol));
+                    if (DEFERRED) asm volatile("v_mov_b32 %0, %1" : "+v"(S.id) : "v"(id));
+                }
                 TRGL_DBG(8, 1);
                 // std::min / std::max keep the first of equal values and +0.0 == -0.0: when the z range ends in a zero its sign is that
                 // of the first zero written in the reference's order (triangle, x, y), see DevStats
@@ -414,6 +430,9 @@ __device__ __forceinline__ void resolve(BlockState& S, unsigned long long pend, 
             }
         }
     }
+#ifdef TRGL_DEBUG_COUNTERS
+    S.dbg[14] += __builtin_amdgcn_s_memtime() - t_res;
+#endif
 }
 
 // Rows of a cleared tile without triangles: the clear values, row-contiguous (this is the whole kernel on a clear-only frame, the
@@ -472,7 +491,7 @@ __device__ __forceinline__ void clear_rows(const FrameParams& fp, int lane, int 
 //   bits 0-23 tile, bits 24-25 row of blocks inside the tile, bit 31: the tile has no triangles and is only cleared
 #define TRGL_ITEM_CLEAR 0x80000000u
 #ifndef TRGL_RASTER_WAVES
-#define TRGL_RASTER_WAVES 6        // waves per SIMD the register allocation of k_raster aims at (80 vector registers)
+#define TRGL_RASTER_WAVES 5        // waves per SIMD the register allocation of k_raster aims at (96 vector registers; 80 spill: measured slower)
 #endif
 
 // BPP: the framebuffer's bytes per pixel when the kernel is compiled for one (3 or 4, FLAT only), 0 = read from FrameParams
@@ -531,10 +550,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
     S.color = fp.clear_color;
     S.id = 0xffffffffu;
     S.pux = 0.0; S.puy = 0.0; S.ptri = 0;
+    S.puz = -1.0; S.pruz = -1.0; S.pz0 = 0.0; S.pz1 = 0.0; S.pz2 = 0.0; S.wtri = 0xffffffffu;
     S.frags = 0; S.zmin = __builtin_inf(); S.zmax = -__builtin_inf();
     const bool zero_locked = stats->zero_locked != 0;
 #ifdef TRGL_DEBUG_COUNTERS
     for (int k = 0; k < 16; ++k) S.dbg[k] = 0;
+    S.t_prev = __builtin_amdgcn_s_memtime();
 #endif
     unsigned long long pend = 0;                          // lanes that hold a deferred fragment (wave-uniform)
 
@@ -560,6 +581,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
     if (beg < end) load_step(p_first, tri_n, cand_n);
     for (uint32_t p0 = p_first; p0 < end; p0 += 256) {
         const uint4 tri_c = tri_n; const uint32_t cand_c = cand_n;
+        TRGL_STAMP(10);            // startup (first step) / whatever is left between the stamps below
         load_step(p0 + 256, tri_n, cand_n);               // (past the end: clamped index, no candidates)
         // append the step's candidates to the ring in list order: entry 4 l + j comes after every entry of the lanes below l
         {
@@ -583,6 +605,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
             }
         }
         const bool last = p0 + 256 >= end;
+        TRGL_STAMP(11);            // list step: wait for its entries, append the candidates
         while (cnt >= 64 || (last && cnt)) {
             const uint32_t n = cnt < 64 ? cnt : 64;
             __builtin_amdgcn_wave_barrier();
@@ -636,6 +659,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
             }
             unsigned long long surv = __ballot(keep);
             TRGL_DBG(1, __popcll(surv));
+            TRGL_STAMP(12);        // cull round (ring read, gather, tests)
             // ---- visits: the survivors in list order, constants through the scalar cache one visit ahead -------------------
             // One visit = our_gl.cpp:147-152 for one triangle on this block, one pixel per lane, up to the coverage decision.
             auto visit = [&](const TriScan& T, uint32_t tcur) {
@@ -643,9 +667,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                 auto note = [&](unsigned long long m, double ux, double uy) {
                     unsigned long long sv;
                     asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\tv_mov_b64 %[px], %[ux]\n\tv_mov_b64 %[py], %[uy]\n\t"
-                                 "v_mov_b32 %[pt], %[t]\n\ts_mov_b64 exec, %[sv]"
-                                 : [px] "+v"(S.pux), [py] "+v"(S.puy), [pt] "+v"(S.ptri), [sv] "=&s"(sv)
-                                 : [ux] "v"(ux), [uy] "v"(uy), [t] "s"(tcur), [m] "s"(m));
+                                 "v_mov_b32 %[pt], %[t]\n\tv_mov_b64 %[puz], %[uz]\n\tv_mov_b64 %[pruz], %[ruz]\n\t"
+                                 "v_mov_b64 %[pz0], %[z0]\n\tv_mov_b64 %[pz1], %[z1]\n\tv_mov_b64 %[pz2], %[z2]\n\ts_mov_b64 exec, %[sv]"
+                                 : [px] "+v"(S.pux), [py] "+v"(S.puy), [pt] "+v"(S.ptri), [sv] "=&s"(sv),
+                                   [puz] "+v"(S.puz), [pruz] "+v"(S.pruz), [pz0] "+v"(S.pz0), [pz1] "+v"(S.pz1), [pz2] "+v"(S.pz2)
+                                 : [ux] "v"(ux), [uy] "v"(uy), [t] "s"(tcur), [m] "s"(m),
+                                   [uz] "s"(T.uz), [ruz] "s"(T.ruz), [z0] "s"(T.z0), [z1] "s"(T.z1), [z2] "s"(T.z2));
                 };
                 double ux, uy;
                 unsigned long long cm;                    // lanes with a covered pixel that can still win the z-test (wave-uniform)
@@ -710,19 +737,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                         "v_mov_b64 %[pux], %[ux]\n\t"
                         "v_mov_b64 %[puy], %[uy]\n\t"
                         "v_mov_b32 %[ptri], %[tcur]\n\t"
+                        "v_mov_b64 %[puz], %[uz]\n\t"
+                        "v_mov_b64 %[pruz], %[ruz]\n\t"
+                        "v_mov_b64 %[pz0], %[z0]\n\t"
+                        "v_mov_b64 %[pz1], %[z1]\n\t"
+                        "v_mov_b64 %[pz2], %[z2]\n\t"
                         "s_mov_b64 exec, %[sx]\n\t"
                         "s_branch .Lvisit_done%=\n"
                         ".Lvisit_end%=:\n\t"
                         "s_mov_b64 %[both], 0\n"
                         ".Lvisit_done%=:"
                         : [cm] "=&s"(cm), [ux] "=&v"(ux), [uy] "=&v"(uy), [s0z] "=&v"(s0z), [s1z] "=&v"(s1z), [ta] "=&v"(ta), [tb] "=&v"(tb2), [tt] "=&v"(tt),
-                          [both] "=&s"(both), [sv] "=&s"(sv), [sx] "=&s"(sx), [pend] "+s"(pend), [pux] "+v"(S.pux), [puy] "+v"(S.puy), [ptri] "+v"(S.ptri)
+                          [both] "=&s"(both), [sv] "=&s"(sv), [sx] "=&s"(sx), [pend] "+s"(pend), [pux] "+v"(S.pux), [puy] "+v"(S.puy), [ptri] "+v"(S.ptri),
+                          [puz] "+v"(S.puz), [pruz] "+v"(S.pruz), [pz0] "+v"(S.pz0), [pz1] "+v"(S.pz1), [pz2] "+v"(S.pz2)
 #ifdef TRGL_DEBUG_COUNTERS
                           , [am] "=&s"(am)
 #endif
                         : [xy] "v"(S.xy), [pxc] "v"(S.pxc), [pyc] "v"(S.pyc), [z] "v"(S.z), [tcur] "s"(tcur),
                           [bx] "s"(T.bx), [ext] "s"(ext), [ax] "s"(T.ax), [ay] "s"(T.ay), [c0] "s"(T.c0), [g1] "s"(T.g1), [g2] "s"(T.g2),
-                          [s0x] "s"(T.s0x), [s0y] "s"(T.s0y), [s1x] "s"(T.s1x), [s1y] "s"(T.s1y), [uz] "s"(T.uz)
+                          [s0x] "s"(T.s0x), [s0y] "s"(T.s0y), [s1x] "s"(T.s1x), [s1y] "s"(T.s1y), [uz] "s"(T.uz),
+                          [ruz] "s"(T.ruz), [z0] "s"(T.z0), [z1] "s"(T.z1), [z2] "s"(T.z2)
                         : "vcc", "scc");
                 } else {
                     // a triangle that is not well scaled: the same visit from C++, coverage from the literal quotients of :85
@@ -779,11 +813,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                     asm volatile("" :: "s"(A.dl));
                 }
             }
+            TRGL_STAMP(13);        // visits of the round (resolves included; their own clock is counter 14)
         }
     }
     if (pend) resolve<KIND, ALLWS, DEFERRED>(S, pend, recs, recs_w, draws, stats, zero_locked);
 
+    TRGL_STAMP(13);
     // ---- block out: every owned pixel once ---------------------------------------------------------------------------
+    // FLAT / PHONG / EYE flushes: the colour (or owner id) of the pixel's winning triangle, fetched here, once per pixel
+    {
+        constexpr bool LATE = KIND == TRGL_SHADER_FLAT || KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE;
+        if (LATE && S.wtri != 0xffffffffu) {
+            const uint2 cd = *reinterpret_cast<const uint2*>(&recs[S.wtri].color);          // color, dl
+            if (KIND == TRGL_SHADER_FLAT) S.color = cd.x; else S.id = TRGL_DL_ID(cd.y);
+        }
+    }
     // depth: 8 B per lane, a row of the block is 64 contiguous bytes
     if (owned) __builtin_nontemporal_store(S.z, &fp.zb[pix]);
     if (DEFERRED && fp.idbuf && owned) fp.idbuf[pix] = S.id;
@@ -819,6 +863,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
         }
     }
 
+    TRGL_STAMP(15);                // block out
     // ---- stats: our_gl.cpp:194-198, reduced per wave, then per workgroup: one partial per work item (k_fold_stats) ------
     uint32_t frags = S.frags;
     unsigned long long kmin = zkey(S.zmin), kmax = zkey(S.zmax);
