@@ -124,7 +124,10 @@ int main(int argc, char** argv) {
         flat.color = TGAColor(uint8_t(p >> 16), uint8_t(p >> 8), uint8_t(p), uint8_t(p >> 24));
         rasterize(tri, flat, framebuffer);
     }
-    gl_flush(framebuffer);
+    if (!gl_flush(framebuffer)) {                            // a C-ABI error anywhere above ends up here, not in abort()
+        std::fprintf(stderr, "demo_main: %s (code %d)\n", gl_last_error_message(), gl_last_error());
+        return 4;
+    }
     if (argc > 3) framebuffer.write_tga_file(argv[3]);       // main.cpp:743
     if (argc > 4) {                                          // main.cpp:751-785: zbuffer.tga, ao.tga, final.tga
         TGAImage zimg, ao_map, final_result;

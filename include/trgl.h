@@ -150,6 +150,22 @@ int trgl_set_strip(trgl_ctx* ctx, int y0, int y1);
  * returns to a single strip. */
 int trgl_set_interleave(trgl_ctx* ctx, int band_rows, int rank, int world);
 
+/* Multi-GPU, the exchange step: join the rows that the `world` contexts of a render own (one process and one context per GPU,
+ * trgl_set_strip with equal strips or trgl_set_interleave) into EVERY context's framebuffer - and z-buffer when `with_z` - by
+ * in-place RCCL all-gathers over xGMI, queued on the context's stream behind the flush they follow (the call itself does not
+ * wait: trgl_sync / trgl_read_framebuffer do).  One all-gather for strips, one per period of world * band_rows rows for bands.
+ * This is the north-star's "RCCL all-gather of tile strips for the final TGAImage" behind the C ABI; a C++ host needs no RCCL
+ * headers: `comm` comes from trgl_rccl_comm_create below (or is any ncclComm_t of `world` ranks the caller already has).
+ * librccl.so.1 is loaded when first needed; TRGL_E_UNSUPPORTED if it is absent. */
+int trgl_gather(trgl_ctx* ctx, void* nccl_comm, int rank, int world, int with_z);
+/* The RCCL bootstrap for a C host: rank 0 obtains an id (128 bytes) and hands it to the other processes by whatever means
+ * the launcher has (a file, a pipe, MPI); every rank then creates its communicator.  Wrap ncclGetUniqueId /
+ * ncclCommInitRank / ncclCommDestroy. */
+#define TRGL_RCCL_ID_BYTES 128
+int trgl_rccl_unique_id(uint8_t id[TRGL_RCCL_ID_BYTES]);
+int trgl_rccl_comm_create(const uint8_t id[TRGL_RCCL_ID_BYTES], int rank, int world, int device, void** nccl_comm);
+int trgl_rccl_comm_destroy(void* nccl_comm);
+
 /* ---- submission ---------------------------------------------------------------------------- */
 
 /* Replaces: n consecutive calls of rasterize(clip, shader, framebuffer) (our_gl.h:58,

@@ -20,8 +20,8 @@ REF_HARNESS = os.path.join(HERE, "_ref", "ref_harness")
 REF_HARNESS_FAST = os.path.join(HERE, "_ref", "ref_harness_fast")   # -O3 -DNDEBUG build, for cpu_baseline timing
 
 MAX_TEXTURES = 16
-FLAT, GOURAUD, PHONG, EYE = 0, 1, 2, 3
-VARY = {FLAT: 0, GOURAUD: 3, PHONG: 24, EYE: 24}
+FLAT, GOURAUD, PHONG, EYE, CHECKER = 0, 1, 2, 3, 4
+VARY = {FLAT: 0, GOURAUD: 3, PHONG: 24, EYE: 24, CHECKER: 0}
 
 
 class Uniforms(C.Structure):
@@ -53,7 +53,7 @@ class Target(C.Structure):
 
 
 def make_uniforms(model_view=None, key=(0, 0, 1), fill=(0, 0, 1), rim=(0, 0, 1), normal_map_strength=1.0,
-                  tex_diffuse=-1, tex_normal=-1, tex_specular=-1) -> Uniforms:
+                  tex_diffuse=-1, tex_normal=-1, tex_specular=-1, cells=0) -> Uniforms:
     u = Uniforms()
     mv = np.eye(4) if model_view is None else np.asarray(model_view, np.float64)
     u.model_view[:] = mv.reshape(16).tolist()
@@ -61,7 +61,7 @@ def make_uniforms(model_view=None, key=(0, 0, 1), fill=(0, 0, 1), rim=(0, 0, 1),
     u.fill_light_dir_eye[:] = list(map(float, fill))
     u.rim_light_dir_eye[:] = list(map(float, rim))
     u.normal_map_strength = float(normal_map_strength)
-    u.tex_diffuse, u.tex_normal, u.tex_specular, u.reserved = tex_diffuse, tex_normal, tex_specular, 0
+    u.tex_diffuse, u.tex_normal, u.tex_specular, u.reserved = tex_diffuse, tex_normal, tex_specular, int(cells)      # cells: CHECKER only
     return u
 
 

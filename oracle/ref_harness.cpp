@@ -10,7 +10,7 @@
 // (our_gl.cpp:18-22).
 //
 // Shaders here are IShader subclasses (our_gl.h:36-52):
-//   FLAT / GOURAUD are defined on the reference's own TGAColor (tgaimage.h:29-63);
+//   FLAT / GOURAUD / CHECKER are defined on the reference's own TGAColor (tgaimage.h:29-63); CHECKER is the one that discards;
 //   PHONG / EYE call the C restatement's fragment (orc_fragment): main.cpp cannot be compiled here
 //   (model.h includes Assimp), so those bodies are NOT pinned by this harness — what it pins for
 //   them is everything around the up-call: the perspective-correct bary handed to fragment(), the
@@ -61,6 +61,16 @@ struct GouraudShader : IShader {
     }
 };
 
+// The discarding kind (include/trgl.h, TRGL_SHADER_CHECKER): exercises `if (discard) continue;` of the reference's rasterize()
+// (our_gl.cpp:187-188) - no depth write, no colour write, no counters for a discarded fragment.
+struct CheckerShader : IShader {
+    TGAColor color; int cells;
+    std::pair<bool, TGAColor> fragment(const vec3 bar) const override {
+        const int a = (int)(bar[0] * cells), c = (int)(bar[1] * cells);
+        return { ((a ^ c) & 1) != 0, color };
+    }
+};
+
 struct RestatedFragShader : IShader {
     int kind; const trgl_uniforms* u; const orc_texture* tex; const double* vary;
     std::pair<bool, TGAColor> fragment(const vec3 bar) const override {
@@ -107,7 +117,8 @@ int run_scene(const char* in_path, const char* out_path) {
         const uint32_t* colors = (const uint32_t*)r.take(n * sizeof(uint32_t));
         r.align8();
 
-        FlatShader flat; GouraudShader gour; RestatedFragShader rest;
+        FlatShader flat; GouraudShader gour; RestatedFragShader rest; CheckerShader chk;
+        chk.cells = u.reserved;
         rest.kind = kind; rest.u = &u; rest.tex = tex.data();
         auto t0 = std::chrono::steady_clock::now();
         for (uint64_t i = 0; i < n; ++i) {
@@ -116,6 +127,9 @@ int run_scene(const char* in_path, const char* out_path) {
             if (kind == TRGL_SHADER_FLAT) {
                 flat.color = color_from_packed(colors[i]);
                 rasterize(tri, flat, framebuffer);
+            } else if (kind == TRGL_SHADER_CHECKER) {
+                chk.color = color_from_packed(colors[i]);
+                rasterize(tri, chk, framebuffer);
             } else if (kind == TRGL_SHADER_GOURAUD) {
                 for (int v = 0; v < 3; ++v) gour.intensity[v] = vary[i * 3 + v];
                 gour.base = color_from_packed(colors[i]);

@@ -249,12 +249,18 @@ static color_t frag_eye(const trgl_uniforms* u, const orc_texture* tx, const dou
     return result;
 }
 
-/* shader.fragment(bary) — the virtual up-call at our_gl.cpp:187, by kind (trgl.h) */
+/* shader.fragment(bary) — the virtual up-call at our_gl.cpp:187, by kind (trgl.h); *discard = the first member of the pair it returns */
 static color_t shade(int kind, const trgl_uniforms* un, const orc_texture* tx, const double* vary,
-                     uint32_t packed_color, const double pc[3]) {
+                     uint32_t packed_color, const double pc[3], int* discard) {
+    *discard = 0;
     switch (kind) {
     case TRGL_SHADER_FLAT:
         return color_from_packed(packed_color);
+    case TRGL_SHADER_CHECKER: {       /* the discarding test kind (trgl.h): cell parities of bar[0] and bar[1] differ -> discard */
+        int a = x86_cvttsd2si(pc[0] * (double)un->reserved), c = x86_cvttsd2si(pc[1] * (double)un->reserved);
+        *discard = ((a ^ c) & 1) != 0;
+        return color_from_packed(packed_color);
+    }
     case TRGL_SHADER_GOURAUD: {
         double intensity = (vary[0] * pc[0] + vary[1] * pc[1]) + vary[2] * pc[2];
         return color_scale(color_from_packed(packed_color), (float)intensity);
@@ -350,7 +356,9 @@ static void rasterize_one(orc_target* t, int kind, const trgl_uniforms* un, cons
                 pc[2] = (bc[2] * inv_w2) / denom;
             }
 
-            color_t color = shade(kind, un, tx, vary, packed_color, pc);              /* :187 */
+            int discard;
+            color_t color = shade(kind, un, tx, vary, packed_color, pc, &discard);    /* :187 */
+            if (discard) continue;                                                    /* :188 */
 
             t->zbuf[idx] = z_ndc;                                                     /* :191 */
             for (int i = 0; i < t->bpp; ++i) t->fb[idx * t->bpp + i] = color.bgra[i]; /* :192, tgaimage.cpp:32-39 */
@@ -364,7 +372,8 @@ static void rasterize_one(orc_target* t, int kind, const trgl_uniforms* un, cons
 
 int orc_fragment(int kind, const trgl_uniforms* u, const orc_texture* tx, const double* vary,
                  uint32_t packed_color, const double bary[3], uint8_t out_bgra[4]) {
-    color_t c = shade(kind, u, tx, vary, packed_color, bary);
+    int discard;
+    color_t c = shade(kind, u, tx, vary, packed_color, bary, &discard);
     memcpy(out_bgra, c.bgra, 4);
     return c.bytespp;
 }

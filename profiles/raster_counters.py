@@ -16,6 +16,7 @@ names = ["candidates (list entries whose bbox reaches the wave's block)", "survi
          "visits with a covered lane (deferred)", "covered lanes that survive the depth plane (deferred fragments)", "resolves", "lanes resolved",
          "fragments written"]
 for n, v in zip(names, out): print(f"{n:82s} {v:>12d}  per triangle {v / N:.3f}")
+print(f"{'list entries that are no triangle of the flush (must be 0)':82s} {out[9]:>12d}")
 tot = sum(out[k] for k in (10, 11, 12, 13, 15))
 for k, n in ((10, "startup + left-over"), (11, "list steps"), (12, "cull rounds"), (13, "visits (with resolves)"), (14, "... of which resolves"), (15, "block out")):
     print(f"{'wave cycles: ' + n:82s} {out[k]:>14d}  {100.0 * out[k] / max(tot, 1):5.1f} %")

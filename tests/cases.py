@@ -7,7 +7,7 @@ Inputs come from tinyrenderder_amd.scenes (bit-reproducible everywhere).
 import numpy as np
 
 from tinyrenderder_amd import scenes
-from tinyrenderder_amd.api import FLAT, GOURAUD, PHONG, EYE, make_uniforms
+from tinyrenderder_amd.api import FLAT, GOURAUD, PHONG, EYE, CHECKER, make_uniforms
 
 DEFAULT_CLEAR = (0, 0, 0, 255)
 
@@ -131,6 +131,24 @@ def huge_depths_128():
     return _case(128, 128, [(FLAT, None, clip, None, col)])
 
 
+def checker_256():
+    """The kind that discards (our_gl.cpp:187-188): fragments whose perspective-correct barycentrics fall on odd checker cells
+    write nothing - no depth, no colour, no counter - so what lies behind them shows through and later fragments are tested against
+    the depth they left alone.  Perspective w makes the perspective-correct barycentrics differ from the screen-space ones."""
+    clip, col = scenes.random_triangles(4000, 256, 256, seed=31, rmin=4, rmax=48, perspective_w=True)
+    return _case(256, 256, [(CHECKER, make_uniforms(cells=6), clip, None, col)])
+
+
+def checker_mixed_200x120():
+    """Discarding and ordinary draws in one flush (per-fragment kinds): flat below, checker in the middle, Gouraud on top."""
+    w, h = 200, 120
+    c0, k0 = scenes.random_triangles(800, w, h, seed=32, rmin=4, rmax=40)
+    c1, k1 = scenes.random_triangles(1500, w, h, seed=33, rmin=4, rmax=40, perspective_w=True)
+    c2, k2 = scenes.random_triangles(600, w, h, seed=34, rmin=2, rmax=24, perspective_w=True)
+    v2 = scenes.SplitMix64(35).uniform(600 * 3, 0.1, 1.2).reshape(600, 3)
+    return _case(w, h, [(FLAT, None, c0, None, k0), (CHECKER, make_uniforms(cells=3), c1, None, k1), (GOURAUD, None, c2, v2, k2)], bpp=4)
+
+
 def empty_scene_64():
     return _case(64, 64, [])
 
@@ -138,7 +156,7 @@ def empty_scene_64():
 CASES = {f.__name__: f for f in (
     flat_small_64, flat_800, flat_persp_512, flat_big_tris_512, edge_256, grid_256, grid_fine_128, gouraud_256_rgba,
     phong_512, phong_nomaps_256, eye_256, multi_draw_320x200, odd_dims_101x67, gray_bpp1_96x64,
-    viewport_offset_256x160, zclear_finite_128, huge_depths_128, empty_scene_64)}
+    viewport_offset_256x160, zclear_finite_128, huge_depths_128, empty_scene_64, checker_256, checker_mixed_200x120)}
 
 # cases whose full buffers are stored in tests/golden/ (small enough to commit)
 FULL_BUFFER_CASES = ("flat_small_64", "odd_dims_101x67", "gray_bpp1_96x64")

@@ -824,3 +824,27 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(partition):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["parity"]["checked"] and d["parity"]["ok"], d["parity"]
+
+
+@pytest.mark.parametrize("partition", ["strips", "bands"])
+def test_c_abi_gather_single_rank_communicator(partition):
+    """trgl_gather (the RCCL all-gather of the north star, behind the C ABI) with the communicator trgl_rccl_comm_create makes:
+    on a one-GPU box that is a 1-rank communicator - the in-place all-gathers run through RCCL for real, over one strip /
+    the bands of one rank - and the frame still equals the oracle's.  (Two ranks need two GPUs: tests/test_multi_rank_cpu.py
+    covers the composition over gloo, examples/demo_multi.cpp is the C++ caller.)"""
+    from tinyrenderder_amd import api
+    case = cases.CASES["flat_persp_512"]()
+    ofb, oz, ost = cases.run_oracle(case)
+    comm = api.rccl_comm_create(api.rccl_unique_id(), 0, 1, 0)
+    try:
+        with api.Context(case["width"], case["height"], case["bpp"]) as ctx:
+            ctx.set_viewport(case["viewport"]); ctx.clear(case["clear"], case["zclear"])
+            if partition == "bands":
+                ctx.set_interleave(64, 0, 1)
+            for kind, u, clip, vary, col in case["draws"]:
+                ctx.draw(kind, clip, vary, col, u)
+            ctx.gather(comm, 0, 1, with_z=True)
+            fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    finally:
+        api.rccl_comm_destroy(comm)
+    assert np.array_equal(z.view(np.uint64), oz.view(np.uint64)) and np.array_equal(fb, ofb) and st == ost

@@ -78,3 +78,39 @@ def test_main_cpp_shaped_demo_matches_oracle(tmp_path, mode):
     assert open(post + "_zbuffer.tga", "rb").read() == orc.tga_encode(orc.zbuffer_image(z))
     assert open(post + "_ao.tga", "rb").read() == orc.tga_encode(ao)
     assert open(post + "_final.tga", "rb").read() == orc.tga_encode(orc.composite(fb, ao))
+
+
+@pytest.mark.gpu
+def test_shim_reports_c_abi_errors_instead_of_aborting():
+    """examples/shim_errors.cpp: a flush beyond 2^32 triangle-tile pairs comes back as gl_flush() == false with
+    gl_last_error() == TRGL_E_UNSUPPORTED; the process lives and the next frame is drawn."""
+    exe = os.path.join(ROOT, "examples", "shim_errors")
+    assert os.path.exists(exe), "examples/shim_errors not built: run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "flush 1: failed, code -5" in r.stdout and "2^32" in r.stdout
+    assert "flush 2: ok, centre pixel 200 100 50" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["strips", "bands"])
+def test_cpp_multi_gpu_host_single_rank(tmp_path, mode):
+    """examples/demo_multi.cpp - one process per GPU over the C ABI, RCCL bootstrap and trgl_gather included - run as a
+    world of ONE on the one-GPU box: the gathered frame and this rank's stats equal the oracle's."""
+    exe = os.path.join(ROOT, "examples", "demo_multi")
+    assert os.path.exists(exe), "examples/demo_multi not built: run __graft_entry__.build()"
+    W, H, bpp = 256, 192, 3
+    clip, col = scenes.random_triangles(3000, W, H, seed=41, rmin=2, rmax=40, perspective_w=True)
+    scene, out = tmp_path / "scene.bin", tmp_path / "out.bin"
+    with open(scene, "wb") as f:
+        f.write(struct.pack("<4i", W, H, bpp, clip.shape[0])); f.write(clip.tobytes()); f.write(col.tobytes())
+    r = subprocess.run([exe, str(scene), str(out), "0", "1", str(tmp_path / "id")] + (["bands"] if mode == "bands" else []),
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, TRGL_DEVICE="0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(str(out) + ".0", "rb").read()
+    fb = np.frombuffer(raw, np.uint8, W * H * bpp).reshape(H, W, bpp)
+    z = np.frombuffer(raw, np.float64, W * H, W * H * bpp).reshape(H, W)
+    o = orc.Oracle(W, H, bpp)
+    o.draw(orc.FLAT, clip, colors=col)
+    assert np.array_equal(z.view(np.uint64), o.z.view(np.uint64)) and np.array_equal(fb, o.fb)
+    assert raw[W * H * bpp + W * H * 8:].decode().strip() == orc.format_stats_line(o.stats)

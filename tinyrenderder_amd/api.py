@@ -14,8 +14,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtrgl.so")
 
-FLAT, GOURAUD, PHONG, EYE = 0, 1, 2, 3
-VARY = {FLAT: 0, GOURAUD: 3, PHONG: 24, EYE: 24}
+FLAT, GOURAUD, PHONG, EYE, CHECKER = 0, 1, 2, 3, 4
+VARY = {FLAT: 0, GOURAUD: 3, PHONG: 24, EYE: 24, CHECKER: 0}
 MEM_HOST, MEM_DEVICE = 0, 1
 PHASE_SETUP, PHASE_BIN, PHASE_RASTER, PHASE_TOTAL, PHASE_RASTER_KERNEL = 0, 1, 2, 3, 4
 NUM_PHASES = 5        # TRGL_NUM_PHASES
@@ -30,6 +30,7 @@ SYMBOLS = [
     "trgl_set_profiling", "trgl_get_phase_ms", "trgl_reset_phase_ms", "trgl_get_last_flush_info",
     "trgl_selftest_division", "trgl_selftest_sampler", "trgl_tga_max_size", "trgl_tga_encode", "trgl_tga_info", "trgl_tga_decode", "trgl_draw_indexed", "trgl_ssao_defaults",
     "trgl_postprocess", "trgl_obj_load", "trgl_obj_free",
+    "trgl_gather", "trgl_rccl_unique_id", "trgl_rccl_comm_create", "trgl_rccl_comm_destroy",
 ]
 
 
@@ -61,7 +62,7 @@ class SsaoParams(C.Structure):
 
 
 def make_uniforms(model_view=None, key=(0, 0, 1), fill=(0, 0, 1), rim=(0, 0, 1), normal_map_strength=1.0,
-                  tex_diffuse=-1, tex_normal=-1, tex_specular=-1) -> Uniforms:
+                  tex_diffuse=-1, tex_normal=-1, tex_specular=-1, cells=0) -> Uniforms:
     u = Uniforms()
     mv = np.eye(4) if model_view is None else np.asarray(model_view, np.float64)
     u.model_view[:] = mv.reshape(16).tolist()
@@ -69,7 +70,7 @@ def make_uniforms(model_view=None, key=(0, 0, 1), fill=(0, 0, 1), rim=(0, 0, 1),
     u.fill_light_dir_eye[:] = list(map(float, fill))
     u.rim_light_dir_eye[:] = list(map(float, rim))
     u.normal_map_strength = float(normal_map_strength)
-    u.tex_diffuse, u.tex_normal, u.tex_specular, u.reserved = tex_diffuse, tex_normal, tex_specular, 0
+    u.tex_diffuse, u.tex_normal, u.tex_specular, u.reserved = tex_diffuse, tex_normal, tex_specular, int(cells)      # cells: CHECKER only
     return u
 
 
@@ -142,12 +143,41 @@ def load_library(path: str = None):
     L.trgl_tga_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_size_t)]
     L.trgl_tga_info.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.trgl_tga_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.trgl_gather.argtypes = [vp, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.trgl_rccl_unique_id.argtypes = [C.c_void_p]
+    L.trgl_rccl_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.trgl_rccl_comm_destroy.argtypes = [C.c_void_p]
     for name in SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int and name not in ("trgl_last_error",):
             f.restype = C.c_int
     _lib = L
     return L
+
+
+def rccl_unique_id() -> bytes:
+    """ncclGetUniqueId through the C ABI: 128 bytes that rank 0 hands to the other ranks."""
+    L = load_library()
+    buf = (C.c_uint8 * 128)()
+    rc = L.trgl_rccl_unique_id(buf)
+    if rc != 0:
+        raise TrglError(f"trgl_rccl_unique_id failed ({rc}): {L.trgl_last_error(None).decode()}")
+    return bytes(buf)
+
+
+def rccl_comm_create(unique_id: bytes, rank: int, world: int, device: int = 0):
+    """ncclCommInitRank through the C ABI; returns the communicator handle for Context.gather()."""
+    L = load_library()
+    comm = C.c_void_p()
+    buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+    rc = L.trgl_rccl_comm_create(buf, rank, world, device, C.byref(comm))
+    if rc != 0:
+        raise TrglError(f"trgl_rccl_comm_create failed ({rc}): {L.trgl_last_error(None).decode()}")
+    return comm
+
+
+def rccl_comm_destroy(comm):
+    load_library().trgl_rccl_comm_destroy(comm)
 
 
 def _ptr(a):
@@ -266,6 +296,11 @@ class Context:
     def set_interleave(self, band_rows, rank, world):
         """Own the bands of `band_rows` rows whose number is `rank` modulo `world` (instead of one strip)."""
         self._chk(self.L.trgl_set_interleave(self.h, band_rows, rank, world))
+
+    def gather(self, comm, rank, world, with_z=False):
+        """trgl_gather: join the rows of the `world` contexts of a render into this context's framebuffer (and z-buffer) with
+        in-place RCCL all-gathers queued on the context's stream; `comm` is an ncclComm_t (rccl_comm_create)."""
+        self._chk(self.L.trgl_gather(self.h, comm, rank, world, int(bool(with_z))))
 
     # ---- submission ----
     def draw(self, kind, clip, varyings=None, colors=None, uniforms=None, n=None, device=False):

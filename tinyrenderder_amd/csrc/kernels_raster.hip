@@ -293,7 +293,11 @@ constexpr int RING = 512;                           // candidate ring of a wave 
 #ifdef TRGL_DEBUG_COUNTERS
 #define TRGL_DBG(i, n) do { S.dbg[i] += (unsigned long long)(n); } while (0)
 // phase clocks of the diagnostic build: the cycles since the last stamp go to counter i
+#ifdef TRGL_DEBUG_NOSTAMP      // (counters 10-13 then describe the first list entry that is no triangle, profiles/one_case.py)
+#define TRGL_STAMP(i) ((void)0)
+#else
 #define TRGL_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); S.dbg[i] += t_ - S.t_prev; S.t_prev = t_; } while (0)
+#endif
 #else
 #define TRGL_DBG(i, n) ((void)0)
 #define TRGL_STAMP(i) ((void)0)
@@ -335,8 +339,7 @@ struct BlockState {
     // constants of the visit, so that resolving them needs no memory access at all - its u.z, 1/u.z and the three vertex depths
     double pux, puy; uint32_t ptri;
     double puz, pruz, pz0, pz1, pz2;
-    uint32_t wtri;          // FLAT / PHONG / EYE flushes: the triangle of the fragment that owns the pixel (its colour / owner id is fetched
-                            // once, at block-out), ~0u = none written in this flush
+    uint32_t pcd;           // ... and its colour (FLAT flushes) or `dl` (all others)
     uint32_t frags; double zmin, zmax;
     int x, y;
     us2 xy;                 // x | y << 16 as two 16-bit words (the bbox test of a visit is packed 16-bit arithmetic)
@@ -355,9 +358,9 @@ __device__ __forceinline__ void resolve(BlockState& S, unsigned long long pend, 
 #ifdef TRGL_DEBUG_COUNTERS
     const unsigned long long t_res = __builtin_amdgcn_s_memtime();
 #endif
-    // LATE: every fragment of the flush is FLAT, PHONG or EYE: its colour / owner id depends on the triangle only, so the lane just
-    // remembers the winning triangle and block-out fetches colour or id once per pixel; resolving then touches no memory at all.
-    constexpr bool LATE = KIND == TRGL_SHADER_FLAT || KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE;
+    // PLAIN: every fragment of the flush is FLAT, PHONG or EYE: its colour / owner id depends on the triangle only and rides with the
+    // deferred fragment (S.pcd), so resolving touches no memory at all.
+    constexpr bool PLAIN = KIND == TRGL_SHADER_FLAT || KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE;
     if (__builtin_amdgcn_inverse_ballot_w64(pend)) {
         const double uz = S.puz, ruz = S.pruz, z0 = S.pz0, z1 = S.pz1, z2 = S.pz2;
         const double ux = S.pux, uy = S.puy, us = ux + uy;
@@ -373,12 +376,12 @@ __device__ __forceinline__ void resolve(BlockState& S, unsigned long long pend, 
         }
         const double z = b0 * z0 + b1 * z1 + b2 * z2;                       // :156-158
         if (__builtin_isfinite(z) && (z < S.z)) {                           // :160, :165
-            uint32_t color = 0, id = 0xffffffffu;
+            uint32_t color = S.pcd, id = 0xffffffffu;
             bool discard = false;
-            if (!LATE) {
-                const uint2 cd = *reinterpret_cast<const uint2*>(&recs[S.ptri].color);        // color, dl
-                const uint32_t dl = cd.y;
-                color = cd.x;
+            if (KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE) id = TRGL_DL_ID(S.pcd);
+            if (!PLAIN) {
+                const uint32_t dl = S.pcd;
+                color = recs[S.ptri].color;
                 const DrawDesc* d = draws + TRGL_DL_DRAW(dl);
                 const int kind = KIND == KIND_ANY ? d->kind : KIND;
                 if (kind == TRGL_SHADER_PHONG || kind == TRGL_SHADER_EYE) {
@@ -413,8 +416,8 @@ __device__ __forceinline__ void resolve(BlockState& S, unsigned long long pend, 
                     "v_max_f64 %[zmax], %[zmax], %[z]"                                           // :198
                     : [sz] "+v"(S.z), [fr] "+v"(S.frags), [zmin] "+v"(S.zmin), [zmax] "+v"(S.zmax)
                     : [z] "v"(z));
-                if (LATE) {
-                    asm volatile("v_mov_b32 %0, %1" : "+v"(S.wtri) : "v"(S.ptri));              // :192 (colour / owner at block-out)
+                if (KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE) {
+                    asm volatile("v_mov_b32 %0, %1" : "+v"(S.id) : "v"(id));                    // (the colour comes from k_shade)
                 } else {
                     const uint32_t ncol = (!DEFERRED || id == 0xffffffffu) ? color : S.color;   // :192 (tgaimage.cpp:32-39 at block-out)
                     asm volatile("v_mov_b32 %0, %1" : "+v"(S.color) : "v"(ncol));
@@ -430,7 +433,7 @@ __device__ __forceinline__ void resolve(BlockState& S, unsigned long long pend, 
             }
         }
     }
-#ifdef TRGL_DEBUG_COUNTERS
+#if defined(TRGL_DEBUG_COUNTERS) && !defined(TRGL_DEBUG_NOSTAMP)
     S.dbg[14] += __builtin_amdgcn_s_memtime() - t_res;
 #endif
 }
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                                                 const uint32_t* __restrict__ tile_start,
                                                 const uint32_t* __restrict__ tile_end,
                                                 const DrawDesc* __restrict__ draws, DevStats* __restrict__ stats,
-                                                const uint32_t* __restrict__ items, const uint32_t* __restrict__ n_items,
+                                                const uint4* __restrict__ items, const uint32_t* __restrict__ n_items,
                                                 unsigned long long* __restrict__ item_stats) {
     constexpr bool DEFERRED = KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE || KIND == KIND_ANY;
     __shared__ uint32_t s_ring[4][RING];
@@ -518,7 +521,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
     const uint32_t per = (G + 7u) >> 3, xj = blockIdx.x >> 3;
     const uint32_t g = (blockIdx.x & 7u) * per + xj;
     if (xj >= per || g >= G) return;                      // (block-uniform, like the clear-only exit below: the one barrier at the end is safe)
-    const uint32_t item = items[g];
+    const uint4 item4 = items[g];                         // work item, its tile's slice [beg, end) of the sorted pair list
+    const uint32_t item = item4.x;
     const int t = (int)(item & 0xffffffu);
     const int tile_y = t / fp.tiles_x, tile_x = t - tile_y * fp.tiles_x;
     const int px0 = tile_x << TRGL_TILE_LOG2, py0 = tile_y << TRGL_TILE_LOG2;
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
     S.color = fp.clear_color;
     S.id = 0xffffffffu;
     S.pux = 0.0; S.puy = 0.0; S.ptri = 0;
-    S.puz = -1.0; S.pruz = -1.0; S.pz0 = 0.0; S.pz1 = 0.0; S.pz2 = 0.0; S.wtri = 0xffffffffu;
+    S.puz = -1.0; S.pruz = -1.0; S.pz0 = 0.0; S.pz1 = 0.0; S.pz2 = 0.0; S.pcd = 0;
     S.frags = 0; S.zmin = __builtin_inf(); S.zmax = -__builtin_inf();
     const bool zero_locked = stats->zero_locked != 0;
 #ifdef TRGL_DEBUG_COUNTERS
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
 #endif
     unsigned long long pend = 0;                          // lanes that hold a deferred fragment (wave-uniform)
 
-    const uint32_t beg = tile_start[t], end = tile_end[t];
+    const uint32_t beg = item4.y, end = item4.z;
     uint32_t* ring = s_ring[w];
     uint32_t head = 0, cnt = 0;                           // ring: `cnt` candidates wait from position `head` on
     // The list, 256 entries per step: lane l takes entries 4 l .. 4 l + 3 of the step (one 16-byte load of triangle ids, one 8-byte
@@ -573,7 +577,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
         const uint2 m = *reinterpret_cast<const uint2*>(bmask + p);
         // bit j: entry pl + j is in [beg, end) and its bbox reaches this wave's block
         uint32_t c = ((m.x >> kblk) & 1u) | (((m.x >> (16 + kblk)) & 1u) << 1) | (((m.y >> kblk) & 1u) << 2) | (((m.y >> (16 + kblk)) & 1u) << 3);
-        const uint32_t lo = pl < beg ? min(beg - pl, 4u) : 0u, hi = pl < end ? min(end - pl, 4u) : 0u;   // valid entries of the lane: [lo, hi)
+        // valid entries of the lane: [lo, hi).  (Written without a wrapping subtraction under a select: in the first step of a list
+        // `pl < end ? min(end - pl, 4) : 0` reached the ISA as a saturating 4 - (end - pl), which takes every lane PAST the end for fully
+        // valid - lists shorter than a step then appended whatever followed them in the pair buffer, stale words of an earlier flush
+        // included; profiles/one_case.py with the diagnostic build found it.)
+        const uint32_t lo = min(beg - min(pl, beg), 4u), hi = min(end - min(pl, end), 4u);
         c &= (0xfu << lo) & (0xfu >> (4u - hi));
         cand4 = c;
     };
@@ -599,6 +607,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                 if (cand_c & 4u) ring[pos & (RING - 1)] = tri_c.z;
                 pos += (cand_c >> 2) & 1u;
                 if (cand_c & 8u) ring[pos & (RING - 1)] = tri_c.w;
+#ifdef TRGL_DEBUG_COUNTERS
+                {   // a candidate that is no triangle of the flush: remember where the first one came from
+                    const uint32_t trs[4] = { tri_c.x, tri_c.y, tri_c.z, tri_c.w };
+                    for (int j = 0; j < 4; ++j)
+                        if (((cand_c >> j) & 1u) && trs[j] >= fp.n_tris && atomicCAS(&stats->dbg[10], 0ull, 1ull) == 0ull) {
+                            stats->dbg[11] = ((unsigned long long)(p0 + 4u * (uint32_t)lane + (uint32_t)j) << 32) | trs[j];
+                            stats->dbg[12] = ((unsigned long long)beg << 32) | end;
+                            stats->dbg[13] = ((unsigned long long)(uint32_t)t << 32) | (uint32_t)kblk;
+                        }
+                }
+#endif
                 const uint32_t added = (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
                 cnt += added;
                 TRGL_DBG(0, added);
@@ -618,6 +637,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
             // (as a float rounded up: six v_max_f32 with DPP / permlane operands instead of 64-bit shuffles through LDS)
             const double zmaxb = (double)wave_max_f32(f32_up(S.z));
             bool keep = (uint32_t)lane < n;
+#ifdef TRGL_DEBUG_COUNTERS
+            if (keep && tri >= fp.n_tris) { atomicAdd(&stats->dbg[9], 1ull); keep = false; }      // must stay 0: a list entry that is no triangle
+#endif
             if (keep) {
                 const double2* q = reinterpret_cast<const double2*>(recs + tri);
                 const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
@@ -668,10 +690,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                     unsigned long long sv;
                     asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\tv_mov_b64 %[px], %[ux]\n\tv_mov_b64 %[py], %[uy]\n\t"
                                  "v_mov_b32 %[pt], %[t]\n\tv_mov_b64 %[puz], %[uz]\n\tv_mov_b64 %[pruz], %[ruz]\n\t"
-                                 "v_mov_b64 %[pz0], %[z0]\n\tv_mov_b64 %[pz1], %[z1]\n\tv_mov_b64 %[pz2], %[z2]\n\ts_mov_b64 exec, %[sv]"
+                                 "v_mov_b64 %[pz0], %[z0]\n\tv_mov_b64 %[pz1], %[z1]\n\tv_mov_b64 %[pz2], %[z2]\n\tv_mov_b32 %[pcd], %[cd]\n\ts_mov_b64 exec, %[sv]"
                                  : [px] "+v"(S.pux), [py] "+v"(S.puy), [pt] "+v"(S.ptri), [sv] "=&s"(sv),
-                                   [puz] "+v"(S.puz), [pruz] "+v"(S.pruz), [pz0] "+v"(S.pz0), [pz1] "+v"(S.pz1), [pz2] "+v"(S.pz2)
-                                 : [ux] "v"(ux), [uy] "v"(uy), [t] "s"(tcur), [m] "s"(m),
+                                   [puz] "+v"(S.puz), [pruz] "+v"(S.pruz), [pz0] "+v"(S.pz0), [pz1] "+v"(S.pz1), [pz2] "+v"(S.pz2), [pcd] "+v"(S.pcd)
+                                 : [ux] "v"(ux), [uy] "v"(uy), [t] "s"(tcur), [m] "s"(m), [cd] "s"(KIND == TRGL_SHADER_FLAT ? T.color : T.dl),
                                    [uz] "s"(T.uz), [ruz] "s"(T.ruz), [z0] "s"(T.z0), [z1] "s"(T.z1), [z2] "s"(T.z2));
                 };
                 double ux, uy;
@@ -742,6 +764,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                         "v_mov_b64 %[pz0], %[z0]\n\t"
                         "v_mov_b64 %[pz1], %[z1]\n\t"
                         "v_mov_b64 %[pz2], %[z2]\n\t"
+                        "v_mov_b32 %[pcd], %[cd]\n\t"
                         "s_mov_b64 exec, %[sx]\n\t"
                         "s_branch .Lvisit_done%=\n"
                         ".Lvisit_end%=:\n\t"
@@ -749,14 +772,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                         ".Lvisit_done%=:"
                         : [cm] "=&s"(cm), [ux] "=&v"(ux), [uy] "=&v"(uy), [s0z] "=&v"(s0z), [s1z] "=&v"(s1z), [ta] "=&v"(ta), [tb] "=&v"(tb2), [tt] "=&v"(tt),
                           [both] "=&s"(both), [sv] "=&s"(sv), [sx] "=&s"(sx), [pend] "+s"(pend), [pux] "+v"(S.pux), [puy] "+v"(S.puy), [ptri] "+v"(S.ptri),
-                          [puz] "+v"(S.puz), [pruz] "+v"(S.pruz), [pz0] "+v"(S.pz0), [pz1] "+v"(S.pz1), [pz2] "+v"(S.pz2)
+                          [puz] "+v"(S.puz), [pruz] "+v"(S.pruz), [pz0] "+v"(S.pz0), [pz1] "+v"(S.pz1), [pz2] "+v"(S.pz2), [pcd] "+v"(S.pcd)
 #ifdef TRGL_DEBUG_COUNTERS
                           , [am] "=&s"(am)
 #endif
                         : [xy] "v"(S.xy), [pxc] "v"(S.pxc), [pyc] "v"(S.pyc), [z] "v"(S.z), [tcur] "s"(tcur),
                           [bx] "s"(T.bx), [ext] "s"(ext), [ax] "s"(T.ax), [ay] "s"(T.ay), [c0] "s"(T.c0), [g1] "s"(T.g1), [g2] "s"(T.g2),
                           [s0x] "s"(T.s0x), [s0y] "s"(T.s0y), [s1x] "s"(T.s1x), [s1y] "s"(T.s1y), [uz] "s"(T.uz),
-                          [ruz] "s"(T.ruz), [z0] "s"(T.z0), [z1] "s"(T.z1), [z2] "s"(T.z2)
+                          [ruz] "s"(T.ruz), [z0] "s"(T.z0), [z1] "s"(T.z1), [z2] "s"(T.z2), [cd] "s"(KIND == TRGL_SHADER_FLAT ? T.color : T.dl)
                         : "vcc", "scc");
                 } else {
                     // a triangle that is not well scaled: the same visit from C++, coverage from the literal quotients of :85
@@ -820,14 +843,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
 
     TRGL_STAMP(13);
     // ---- block out: every owned pixel once ---------------------------------------------------------------------------
-    // FLAT / PHONG / EYE flushes: the colour (or owner id) of the pixel's winning triangle, fetched here, once per pixel
-    {
-        constexpr bool LATE = KIND == TRGL_SHADER_FLAT || KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE;
-        if (LATE && S.wtri != 0xffffffffu) {
-            const uint2 cd = *reinterpret_cast<const uint2*>(&recs[S.wtri].color);          // color, dl
-            if (KIND == TRGL_SHADER_FLAT) S.color = cd.x; else S.id = TRGL_DL_ID(cd.y);
-        }
-    }
     // depth: 8 B per lane, a row of the block is 64 contiguous bytes
     if (owned) __builtin_nontemporal_store(S.z, &fp.zb[pix]);
     if (DEFERRED && fp.idbuf && owned) fp.idbuf[pix] = S.id;
@@ -899,12 +914,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
 template <int KIND>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade(FrameParams fp, const TriRec* __restrict__ recs, const TriW* __restrict__ recs_w,
                                                 const DrawDesc* __restrict__ draws,
-                                                const DevTexture* __restrict__ tex, const uint32_t* __restrict__ items,
+                                                const DevTexture* __restrict__ tex, const uint4* __restrict__ items,
                                                 const uint32_t* __restrict__ n_items) {
     const int lane = threadIdx.x & 63;
     const uint32_t item_idx = blockIdx.x;                // one 256-thread block per work item: wave w shades block w of the item's row
     if (item_idx >= *n_items) return;
-    const uint32_t item = items[item_idx];
+    const uint32_t item = items[item_idx].x;
     if (item & TRGL_ITEM_CLEAR) return;                  // no triangles: no owners
     const int t = (int)(item & 0xffffffu);
     const int tile_y = t / fp.tiles_x, tile_x = t - tile_y * fp.tiles_x;
@@ -1030,14 +1045,16 @@ __global__ void k_selftest_sampler(const DevTexture* __restrict__ tex, int slot,
 // does not start from clear, and block rows entirely outside the strip get no item.
 __global__ __launch_bounds__(256) void k_make_items(FrameParams fp, const uint32_t* __restrict__ tile_start,
                                                     const uint32_t* __restrict__ tile_end,
-                                                    uint32_t* __restrict__ items, uint32_t* __restrict__ n_items) {
+                                                    uint4* __restrict__ items, uint32_t* __restrict__ n_items) {
     const int ntiles_strip = (fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t nb = 0, t = 0, rows = 0;          // rows: bit r set = block row r of the tile gets an item
+    uint32_t beg = 0, end = 0;
     bool clear_only = false;
     if (k < ntiles_strip) {
         t = (uint32_t)(fp.strip_ty0 * fp.tiles_x + k);
-        const uint32_t n = tile_end[t] - tile_start[t];
+        beg = tile_start[t]; end = tile_end[t];
+        const uint32_t n = end - beg;
         const int ty = (int)(t / (uint32_t)fp.tiles_x);
         if ((n || fp.init_from_clear) && tile_row_owned(fp, ty)) {
             if (n) {
@@ -1057,8 +1074,9 @@ __global__ __launch_bounds__(256) void k_make_items(FrameParams fp, const uint32
     uint32_t base = 0;
     if (lane == 63 && total) base = atomicAdd(n_items, total);
     base = __shfl(base, 63) + inc - nb;
-    if (clear_only) items[base] = t | TRGL_ITEM_CLEAR;
-    else for (uint32_t r = 0; r < 4; ++r) if ((rows >> r) & 1u) items[base++] = t | (r << 24);
+    // (an item carries its tile's slice of the pair list: one dependent load less at the start of every raster wave)
+    if (clear_only) items[base] = make_uint4(t | TRGL_ITEM_CLEAR, 0u, 0u, 0u);
+    else for (uint32_t r = 0; r < 4; ++r) if ((rows >> r) & 1u) items[base++] = make_uint4(t | (r << 24), beg, end, 0u);
 }
 
 // after the raster kernel of a flush: fold the per-item partials into the context's counters
@@ -1124,7 +1142,7 @@ uint32_t raster_max_items(const FrameParams& fp) { return owned_tiles(fp) * 4u; 
 void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER_* if uniform over the flush, else -1 */, bool all_well_scaled,
                    const TriRec* recs, const TriW* recs_w, const uint32_t* vals, const uint16_t* bmask,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
-                   const DevTexture* tex, DevStats* stats, uint32_t max_items, uint32_t* items,
+                   const DevTexture* tex, DevStats* stats, uint32_t max_items, uint4* items,
                    uint32_t* n_items, unsigned long long* item_stats, hipEvent_t ev_before, hipEvent_t ev_after) {
     const int tiles = (fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x;
     if (tiles <= 0 || max_items == 0) {          // a context that owns no rows (a rank beyond the image's bands): nothing to draw

@@ -34,7 +34,7 @@ uint32_t raster_max_items(const FrameParams& fp);   // work items (workgroups of
 void launch_raster(hipStream_t s, const FrameParams& fp, int kind, bool all_well_scaled, const TriRec* recs, const TriW* recs_w,
                    const uint32_t* vals, const uint16_t* bmask,
                    const uint32_t* tile_start, const uint32_t* tile_end, const DrawDesc* draws,
-                   const DevTexture* tex, DevStats* stats, uint32_t max_items, uint32_t* items,
+                   const DevTexture* tex, DevStats* stats, uint32_t max_items, uint4* items,
                    uint32_t* n_items, unsigned long long* item_stats, hipEvent_t ev_before = nullptr,
                    hipEvent_t ev_after = nullptr);     // optional events recorded right around the k_raster launch
 

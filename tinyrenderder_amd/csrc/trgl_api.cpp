@@ -5,6 +5,7 @@
 // and is the batched equivalent of the reference's per-face loop of rasterize() calls
 // (main.cpp:660-666): submission order is preserved per tile, so results are identical.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -64,7 +65,7 @@ struct trgl_ctx {
     uint32_t* hist = nullptr; size_t cap_hist = 0;
     uint32_t* scan_tmp = nullptr; size_t cap_scan = 0;
     uint32_t* tile_start = nullptr; uint32_t* tile_end = nullptr;
-    uint32_t* items = nullptr; size_t cap_items = 0; uint32_t* n_items = nullptr;
+    uint4* items = nullptr; size_t cap_items = 0; uint32_t* n_items = nullptr;
     unsigned long long* item_stats = nullptr; size_t cap_item_stats = 0;
     DrawDesc* draws_dev = nullptr;
     DrawDesc* draws_pinned = nullptr;
@@ -501,6 +502,7 @@ int trgl_flush_begin(trgl_ctx* c) {
     if (c->strip_y1 <= c->strip_y0) fp.strip_ty1 = fp.strip_ty0;
     fp.il_tiles = c->il_tiles; fp.il_world = c->il_world; fp.il_rank = c->il_rank;
     fp.init_from_clear = c->clear_pending ? 1 : 0;
+    fp.n_tris = (uint32_t)c->queued_tris;
     fp.clear_color = c->clear_color; fp.clear_z = c->clear_z;
     std::memcpy(fp.vp, c->vp, sizeof(fp.vp));
 
@@ -594,6 +596,11 @@ int trgl_flush_end(trgl_ctx* c) {
     if ((r = grow(c, c->item_stats, c->cap_item_stats, ((size_t)max_items + 64) * 4))) return r;
     // k_setup counted the triangles that are not well scaled (it came over with the pair count): without any, the kernel without the literal path
     const bool all_well_scaled = N == 0 || c->stats_pinned->literal_tris == 0;
+    if (std::getenv("TRGL_DEBUG_PTRS")) {        // diagnostics: where the buffers of this flush live
+        std::fprintf(stderr, "trgl ptrs: fb %p +%zu  zb %p +%zu  recs %p +%zu  recs_w %p  vals %p bmask %p cap_pairs %zu P %u  items %p cap %zu  item_stats %p  tile_start %p  N %llu max_items %u\n",
+                     (void*)c->fb, (size_t)c->W * c->H * c->bpp, (void*)c->zb, (size_t)c->W * c->H * 8, (const void*)recs_arg, c->cap_tris * sizeof(TriRec), (void*)c->recs_w,
+                     (const void*)vals_arg, (const void*)bmask_arg, c->cap_pairs, P, (void*)c->items, c->cap_items, (void*)c->item_stats, (void*)c->tile_start, (unsigned long long)N, max_items);
+    }
     launch_raster(s, fp, flush_kind, all_well_scaled, recs_arg, c->recs_w, vals_arg, bmask_arg, c->tile_start, c->tile_end, c->draws_dev, c->tex_dev, c->stats_dev,
                   max_items, c->items, c->n_items, c->item_stats,
                   c->profiling ? c->ev[4] : nullptr, c->profiling ? c->ev[5] : nullptr);
@@ -827,6 +834,112 @@ extern "C" int trgl_debug_counters(trgl_ctx* c, unsigned long long out[16]) {
     int r = flush_sync(c); if (r) return r;
     HIPCHK(c, hipMemcpy(c->stats_pinned, c->stats_dev, sizeof(DevStats), hipMemcpyDeviceToHost));
     for (int k = 0; k < 16; ++k) out[k] = c->stats_pinned->dbg[k];
+    return TRGL_OK;
+}
+
+}  // extern "C"
+
+// ---- RCCL, loaded on demand (the library has no link-time dependency on it) --------------------------------------------
+namespace {
+struct Rccl {
+    struct Id { char b[128]; };          // ncclUniqueId, passed by value (rccl.h)
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+Rccl& rccl() {
+    static Rccl r;
+    if (!r.lib) {
+        r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!r.lib) r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) {
+            r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+            r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+            r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+            r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+            r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
+            r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
+            r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+            r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GroupStart && r.GroupEnd;
+        }
+    }
+    return r;
+}
+std::string rccl_err(const char* what, int code) {
+    Rccl& r = rccl();
+    return std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(code) : "RCCL error") + " (" + std::to_string(code) + ")";
+}
+constexpr int NCCL_UINT8 = 1;       // ncclUint8 (rccl.h, ncclDataType_t)
+}  // namespace
+
+extern "C" {
+
+int trgl_rccl_unique_id(uint8_t id[TRGL_RCCL_ID_BYTES]) {
+    if (!id) return TRGL_E_INVALID;
+    Rccl& r = rccl();
+    if (!r.ok) { g_create_error = "librccl.so.1 could not be loaded"; return TRGL_E_UNSUPPORTED; }
+    const int rc = r.GetUniqueId(id);
+    if (rc) { g_create_error = rccl_err("ncclGetUniqueId", rc); return TRGL_E_HIP; }
+    return TRGL_OK;
+}
+int trgl_rccl_comm_create(const uint8_t id[TRGL_RCCL_ID_BYTES], int rank, int world, int device, void** comm) {
+    if (!id || !comm || world < 1 || rank < 0 || rank >= world) return TRGL_E_INVALID;
+    Rccl& r = rccl();
+    if (!r.ok) { g_create_error = "librccl.so.1 could not be loaded"; return TRGL_E_UNSUPPORTED; }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return TRGL_E_HIP; }
+    Rccl::Id uid; std::memcpy(uid.b, id, 128);
+    const int rc = r.CommInitRank(comm, world, uid, rank);
+    if (rc) { g_create_error = rccl_err("ncclCommInitRank", rc); return TRGL_E_HIP; }
+    return TRGL_OK;
+}
+int trgl_rccl_comm_destroy(void* comm) {
+    if (!comm) return TRGL_E_INVALID;
+    Rccl& r = rccl();
+    if (!r.ok) return TRGL_E_UNSUPPORTED;
+    return r.CommDestroy(comm) ? TRGL_E_HIP : TRGL_OK;
+}
+
+int trgl_gather(trgl_ctx* c, void* comm, int rank, int world, int with_z) {
+    CHKCTX(c);
+    if (!comm || world < 1 || rank < 0 || rank >= world) return fail(c, TRGL_E_INVALID, "trgl_gather: bad communicator / rank / world");
+    Rccl& r = rccl();
+    if (!r.ok) return fail(c, TRGL_E_UNSUPPORTED, "trgl_gather: librccl.so.1 could not be loaded");
+    int fr = trgl_flush(c); if (fr) return fr;               // the rows this context owns are complete behind this point of the stream
+    const size_t row_fb = (size_t)c->W * c->bpp, row_z = (size_t)c->W * sizeof(double);
+    int rc = 0;
+    if (c->il_tiles == 0) {
+        // one strip per rank: equal, contiguous chunks of the row-major buffers
+        if (c->H % world) return fail(c, TRGL_E_INVALID, "trgl_gather: the height is not divisible by the number of ranks (equal strips are required)");
+        const int rows = c->H / world;
+        if (c->strip_y0 != rank * rows || c->strip_y1 != (rank + 1) * rows)
+            return fail(c, TRGL_E_STATE, "trgl_gather: this context's strip is not rows [rank * H / world, (rank + 1) * H / world)");
+        if ((rc = r.GroupStart())) { c->err = rccl_err("ncclGroupStart", rc); return TRGL_E_HIP; }
+        rc = r.AllGather(c->fb + (size_t)c->strip_y0 * row_fb, c->fb, (size_t)rows * row_fb, NCCL_UINT8, comm, c->stream);
+        if (!rc && with_z) rc = r.AllGather(reinterpret_cast<uint8_t*>(c->zb) + (size_t)c->strip_y0 * row_z, c->zb, (size_t)rows * row_z, NCCL_UINT8, comm, c->stream);
+        const int rc2 = r.GroupEnd();
+        if (!rc) rc = rc2;
+    } else {
+        // interleaved bands: inside each period of world * band_rows rows the bands lie in rank order
+        if (c->il_world != world || c->il_rank != rank) return fail(c, TRGL_E_STATE, "trgl_gather: rank / world differ from trgl_set_interleave");
+        const int band = c->il_tiles * TRGL_TILE, period = band * world;
+        if (c->H % period) return fail(c, TRGL_E_INVALID, "trgl_gather: the height is not a multiple of world * band_rows");
+        if ((rc = r.GroupStart())) { c->err = rccl_err("ncclGroupStart", rc); return TRGL_E_HIP; }
+        for (int p0 = 0; p0 < c->H && !rc; p0 += period) {
+            const int y0 = p0 + rank * band;
+            rc = r.AllGather(c->fb + (size_t)y0 * row_fb, c->fb + (size_t)p0 * row_fb, (size_t)band * row_fb, NCCL_UINT8, comm, c->stream);
+            if (!rc && with_z) rc = r.AllGather(reinterpret_cast<uint8_t*>(c->zb) + (size_t)y0 * row_z, reinterpret_cast<uint8_t*>(c->zb) + (size_t)p0 * row_z,
+                                                (size_t)band * row_z, NCCL_UINT8, comm, c->stream);
+        }
+        const int rc2 = r.GroupEnd();
+        if (!rc) rc = rc2;
+    }
+    if (rc) { c->err = rccl_err("ncclAllGather", rc); return TRGL_E_HIP; }
     return TRGL_OK;
 }
 

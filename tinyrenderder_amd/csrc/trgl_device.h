@@ -100,6 +100,7 @@ struct FrameParams {
     int32_t  strip_ty0, strip_ty1;    // tile rows intersecting the strip: [ty0, ty1)
     int32_t  il_tiles, il_world, il_rank;   // interleaved ownership (trgl_set_interleave): bands of il_tiles tile rows dealt round-robin to
                                       // il_world contexts, this one takes band number == il_rank (mod il_world); il_tiles = 0: the strip above
+    uint32_t n_tris;                  // triangles of the flush (diagnostic builds check list entries against it)
     int32_t  init_from_clear;         // 1: tiles start from the clear values, not from HBM
     uint32_t clear_color;             // packed BGRA
     double   clear_z;

@@ -16,11 +16,16 @@
 //   * a C++ virtual cannot be called from a kernel: IShader gains describe(), returning the POD descriptor of a
 //     shader kind the device implements (trgl_shaders.h: FlatShader, GouraudShader, PhongShader, EyeShader).
 //     A subclass without one makes rasterize() fail loudly — there is NO CPU fallback.
+//   * errors of the C ABI (out of memory, a flush beyond 2^32 triangle-tile pairs, a HIP error ...) do not end the process: the
+//     call that met one drops its work, gl_flush() / gl_draw_model() / gl_draw_indexed() / gl_postprocess() return false, and
+//     gl_last_error() / gl_last_error_message() tell which (sticky until gl_clear_error()).  Only a programming error - an
+//     IShader without describe() - still aborts.
 // Header-only (C++17 inline variables); link with -ltrgl.
 #pragma once
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
+#include <string>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -121,56 +126,70 @@ struct State {
     std::vector<double> clip, vary;
     std::vector<std::uint32_t> colors;
     mat<4, 4> viewport_at_batch;
+    int err = TRGL_OK;                    // first C-ABI error since gl_clear_error() (a TRGL_E_* code)
+    std::string err_msg;
 };
 inline State& state() { static State s; return s; }
 
-inline void die(const char* what, trgl_ctx* c) {
-    std::fprintf(stderr, "trgl: %s failed: %s\n", what, trgl_last_error(c));
-    std::abort();
+// a C-ABI call failed: remember the first error (code + message); the caller of the shim asks gl_last_error()
+inline bool fail(const char* what, int code, trgl_ctx* c) {
+    State& s = state();
+    if (s.err == TRGL_OK) { s.err = code; s.err_msg = std::string(what) + ": " + trgl_last_error(c); }
+    return false;
 }
-#define TRGL_SHIM_CHK(call) do { if ((call) != TRGL_OK) ::trgl_shim::die(#call, ::trgl_shim::state().ctx); } while (0)
+// evaluates to true when the call succeeded
+#define TRGL_SHIM_OK(call) ([&]() -> bool { const int rc_ = (call); return rc_ == TRGL_OK ? true : ::trgl_shim::fail(#call, rc_, ::trgl_shim::state().ctx); }())
 
 inline int device_from_env() { const char* e = std::getenv("TRGL_DEVICE"); return e ? std::atoi(e) : 0; }
 
 // make sure a context matching the framebuffer exists and holds the host's current pixels / depths
-inline void bind(TGAImage& fb) {
+inline bool bind(TGAImage& fb) {
     State& s = state();
     const int fb_bpp = image_bpp(fb);
     if (s.ctx && (s.w != fb.width() || s.h != fb.height() || s.bpp != fb_bpp)) { trgl_destroy(s.ctx); s.ctx = nullptr; }
     if (!s.ctx) {
-        if (trgl_create(device_from_env(), fb.width(), fb.height(), fb_bpp, &s.ctx) != TRGL_OK) die("trgl_create", nullptr);
+        const int rc = trgl_create(device_from_env(), fb.width(), fb.height(), fb_bpp, &s.ctx);
+        if (rc != TRGL_OK) { s.ctx = nullptr; return fail("trgl_create", rc, nullptr); }
         s.w = fb.width(); s.h = fb.height(); s.bpp = fb_bpp;
-        TRGL_SHIM_CHK(trgl_write_framebuffer(s.ctx, fb.buffer()));
+        if (!TRGL_SHIM_OK(trgl_write_framebuffer(s.ctx, fb.buffer()))) return false;
         s.zbuffer_dirty_on_host = true;
     }
     if (s.zbuffer_dirty_on_host) {
         std::vector<double>& hz = zbuffer.raw();
         if (hz.size() != std::size_t(s.w) * s.h) hz.assign(std::size_t(s.w) * s.h, std::numeric_limits<double>::infinity());
-        TRGL_SHIM_CHK(trgl_write_zbuffer(s.ctx, hz.data()));
+        if (!TRGL_SHIM_OK(trgl_write_zbuffer(s.ctx, hz.data()))) return false;
         s.zbuffer_dirty_on_host = false;
         s.zbuffer_stale_on_host = false;
     }
+    return true;
 }
 
-inline void submit_batch() {
+// hand the batched triangles to the device (on an error the batch is dropped: the call that met it reports false)
+inline bool submit_batch() {
     State& s = state();
-    if (!s.have_batch) return;
+    if (!s.have_batch) return true;
     double vp[16];
     for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) vp[4 * r + c] = s.viewport_at_batch[r][c];
-    TRGL_SHIM_CHK(trgl_set_viewport(s.ctx, vp));
-    TRGL_SHIM_CHK(trgl_draw(s.ctx, s.kind, &s.uniforms, s.clip.data(), s.vary.empty() ? nullptr : s.vary.data(),
-                            s.colors.data(), s.clip.size() / 12, TRGL_MEM_HOST));
+    const bool ok = s.ctx && TRGL_SHIM_OK(trgl_set_viewport(s.ctx, vp)) &&
+                    TRGL_SHIM_OK(trgl_draw(s.ctx, s.kind, &s.uniforms, s.clip.data(), s.vary.empty() ? nullptr : s.vary.data(),
+                                           s.colors.data(), s.clip.size() / 12, TRGL_MEM_HOST));
     s.clip.clear(); s.vary.clear(); s.colors.clear();
     s.have_batch = false;
     s.zbuffer_stale_on_host = true;
+    return ok;
 }
 
 inline int vary_count(int kind) {
-    return kind == TRGL_SHADER_GOURAUD ? TRGL_VARY_GOURAUD : (kind == TRGL_SHADER_PHONG || kind == TRGL_SHADER_EYE) ? TRGL_VARY_PHONG : 0;
+    return kind == TRGL_SHADER_GOURAUD ? TRGL_VARY_GOURAUD : (kind == TRGL_SHADER_PHONG || kind == TRGL_SHADER_EYE) ? TRGL_VARY_PHONG : 0;   // FLAT, CHECKER: 0
 }
 inline bool same_matrix(const mat<4, 4>& a, const mat<4, 4>& b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
 
 }  // namespace trgl_shim
+
+// The first C-ABI error since the last gl_clear_error() (TRGL_OK = none) and its message.
+inline int gl_last_error() { return trgl_shim::state().err; }
+inline const char* gl_last_error_message() { return trgl_shim::state().err_msg.c_str(); }
+inline void gl_clear_error() { trgl_shim::State& s = trgl_shim::state(); s.err = TRGL_OK; s.err_msg.clear(); }
 
 // ---- our_gl.h:25-31 ------------------------------------------------------------------------------
 inline void lookat(const vec3 eye, const vec3 center, const vec3 up) {            // our_gl.cpp:25-41
@@ -206,13 +225,12 @@ inline void trgl_zbuffer_proxy::pull() const {
     if (!s.zbuffer_stale_on_host || s.zbuffer_dirty_on_host) return;
     std::vector<double>& hz = const_cast<std::vector<double>&>(host_);
     hz.resize(std::size_t(s.w) * s.h);
-    TRGL_SHIM_CHK(trgl_read_zbuffer(s.ctx, hz.data()));
-    s.zbuffer_stale_on_host = false;
+    if (TRGL_SHIM_OK(trgl_read_zbuffer(s.ctx, hz.data()))) s.zbuffer_stale_on_host = false;
 }
 inline void trgl_zbuffer_proxy::touched() { trgl_shim::state().zbuffer_dirty_on_host = true; }
 inline void trgl_zbuffer_proxy::assign(std::size_t n, double v) {
     trgl_shim::State& s = trgl_shim::state();
-    if (s.ctx) { trgl_shim::submit_batch(); TRGL_SHIM_CHK(trgl_flush(s.ctx)); }   // earlier draws see the old depths
+    if (s.ctx) { trgl_shim::submit_batch(); (void)TRGL_SHIM_OK(trgl_flush(s.ctx)); }   // earlier draws see the old depths
     host_.assign(n, v);
     s.zbuffer_dirty_on_host = true; s.zbuffer_stale_on_host = false;
 }
@@ -220,32 +238,32 @@ inline void trgl_zbuffer_proxy::assign(std::size_t n, double v) {
 // Tell the shim the host changed the depths behind the proxy's back (through zbuffer.raw()) or the framebuffer's pixels.
 inline void gl_zbuffer_modified() {
     trgl_shim::State& s = trgl_shim::state();
-    if (s.ctx) { trgl_shim::submit_batch(); TRGL_SHIM_CHK(trgl_flush(s.ctx)); }   // what was batched was drawn against the OLD depths
+    if (s.ctx) { trgl_shim::submit_batch(); (void)TRGL_SHIM_OK(trgl_flush(s.ctx)); }   // what was batched was drawn against the OLD depths
     s.zbuffer_dirty_on_host = true;
 }
 inline void gl_framebuffer_modified(TGAImage& fb) {
     trgl_shim::State& s = trgl_shim::state();
-    if (s.ctx) { trgl_shim::submit_batch(); TRGL_SHIM_CHK(trgl_write_framebuffer(s.ctx, fb.buffer())); }
+    if (s.ctx) { trgl_shim::submit_batch(); (void)TRGL_SHIM_OK(trgl_write_framebuffer(s.ctx, fb.buffer())); }
 }
 
 // Model textures live on the device: TGAImage::buffer() layout, one slot per map (include/trgl.h).
-inline void gl_upload_texture(TGAImage& framebuffer, int slot, const TGAImage& img) {
-    trgl_shim::bind(framebuffer);
-    trgl_shim::submit_batch();
-    TRGL_SHIM_CHK(trgl_upload_texture(trgl_shim::state().ctx, slot, trgl_shim::image_bytes(img), img.width(), img.height(), trgl_shim::image_bpp(img)));
+inline bool gl_upload_texture(TGAImage& framebuffer, int slot, const TGAImage& img) {
+    if (!trgl_shim::bind(framebuffer)) return false;
+    const bool ok = trgl_shim::submit_batch();
+    return TRGL_SHIM_OK(trgl_upload_texture(trgl_shim::state().ctx, slot, trgl_shim::image_bytes(img), img.width(), img.height(), trgl_shim::image_bpp(img))) && ok;
 }
 
 // ---- our_gl.h:58 ---------------------------------------------------------------------------------
 inline void rasterize(const Triangle& clip, const IShader& shader, TGAImage& framebuffer) {
     using namespace trgl_shim;
     State& s = state();
-    bind(framebuffer);
     trgl_shader_desc d;
-    if (!shader.describe(d)) {
+    if (!shader.describe(d)) {                                    // a programming error, not a run-time condition
         std::fprintf(stderr, "trgl: rasterize(): this IShader subclass has no device descriptor (describe()); "
                              "the fragment stage runs on the GPU and there is no CPU fallback\n");
         std::abort();
     }
+    if (!bind(framebuffer)) return;                               // (reported through gl_last_error(); rasterize() is void, our_gl.h:58)
     const int K = vary_count(d.kind);
     if (s.have_batch && (s.kind != d.kind || std::memcmp(&s.uniforms, &d.uniforms, sizeof(trgl_uniforms)) != 0 ||
                          !same_matrix(s.viewport_at_batch, Viewport)))
@@ -265,12 +283,12 @@ inline void rasterize(const Triangle& clip, const IShader& shader, TGAImage& fra
 // (main.cpp:71-90 = 199-218: eye = ModelView*(p,1), normal_eye = ModelView*(n,0), clip = Perspective*eye) runs on the
 // device over the indexed mesh.  `vertices`: nv rows of `stride` doubles starting with position[3], normal[3], uv[2]
 // (the reference's Vertex, model.h:14-20, has stride 14); `indices`: 3 per face.
-inline void gl_draw_indexed(const IShader& shader, const double* vertices, int stride, std::size_t nv,
+inline bool gl_draw_indexed(const IShader& shader, const double* vertices, int stride, std::size_t nv,
                             const unsigned int* indices, std::size_t nfaces, TGAImage& framebuffer) {
     using namespace trgl_shim;
     State& s = state();
-    bind(framebuffer);
-    submit_batch();                                             // earlier rasterize() calls come first
+    if (!bind(framebuffer)) return false;
+    bool ok = submit_batch();                                   // earlier rasterize() calls come first
     trgl_shader_desc d;
     if (!shader.describe(d) || (d.kind != TRGL_SHADER_PHONG && d.kind != TRGL_SHADER_EYE)) {
         std::fprintf(stderr, "trgl: gl_draw_indexed(): needs a PHONG or EYE shader with a device descriptor\n");
@@ -278,49 +296,51 @@ inline void gl_draw_indexed(const IShader& shader, const double* vertices, int s
     }
     double vp[16], pj[16];
     for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { vp[4 * r + c] = Viewport[r][c]; pj[4 * r + c] = Perspective[r][c]; }
-    TRGL_SHIM_CHK(trgl_set_viewport(s.ctx, vp));
     static_assert(sizeof(unsigned int) == sizeof(std::uint32_t), "indices are 32-bit");
-    TRGL_SHIM_CHK(trgl_draw_indexed(s.ctx, d.kind, &d.uniforms, pj, vertices, stride, nv,
-                                    reinterpret_cast<const std::uint32_t*>(indices), nfaces, TRGL_MEM_HOST));
+    ok = TRGL_SHIM_OK(trgl_set_viewport(s.ctx, vp)) &&
+         TRGL_SHIM_OK(trgl_draw_indexed(s.ctx, d.kind, &d.uniforms, pj, vertices, stride, nv,
+                                        reinterpret_cast<const std::uint32_t*>(indices), nfaces, TRGL_MEM_HOST)) && ok;
     s.zbuffer_stale_on_host = true;
+    return ok;
 }
 // ... for a model that keeps `vertices` (records of packed doubles) and `indices` as the reference's Model does (model.h:114-115)
-template <class ModelT> inline void gl_draw_model(const ModelT& model, const IShader& shader, TGAImage& framebuffer) {
+template <class ModelT> inline bool gl_draw_model(const ModelT& model, const IShader& shader, TGAImage& framebuffer) {
     using V = typename std::decay<decltype(model.vertices[0])>::type;
     static_assert(sizeof(V) % sizeof(double) == 0, "vertex records must be packed doubles");
-    gl_draw_indexed(shader, reinterpret_cast<const double*>(model.vertices.data()), int(sizeof(V) / sizeof(double)),
+    return gl_draw_indexed(shader, reinterpret_cast<const double*>(model.vertices.data()), int(sizeof(V) / sizeof(double)),
                     model.vertices.size(), model.indices.data(), model.indices.size() / 3, framebuffer);
 }
 
 // Run everything submitted so far and bring the pixels back into the caller's TGAImage (before framebuffer.get(),
 // write_tga_file(), main.cpp:743,773).  The depths follow on demand through the `zbuffer` proxy.
-inline void gl_flush(TGAImage& framebuffer) {
+// false: something submitted since the last gl_flush() failed (gl_last_error()); the pixels hold what could be drawn.
+inline bool gl_flush(TGAImage& framebuffer) {
     using namespace trgl_shim;
     State& s = state();
-    bind(framebuffer);
-    submit_batch();
-    TRGL_SHIM_CHK(trgl_read_framebuffer(s.ctx, framebuffer.buffer()));
+    if (!bind(framebuffer)) return false;
+    const bool ok = submit_batch();
+    return TRGL_SHIM_OK(trgl_read_framebuffer(s.ctx, framebuffer.buffer())) && ok && s.err == TRGL_OK;
 }
 
 // main.cpp:751-785 on the device (z-buffer never leaves HBM): fills the three images the reference writes as
 // zbuffer.tga, ao.tga and final.tga.  Any of the pointers may be null.
-inline void gl_postprocess(TGAImage& framebuffer, TGAImage* zbuffer_image, TGAImage* ao_map, TGAImage* final_result) {
+inline bool gl_postprocess(TGAImage& framebuffer, TGAImage* zbuffer_image, TGAImage* ao_map, TGAImage* final_result) {
     using namespace trgl_shim;
     State& s = state();
-    bind(framebuffer);
-    submit_batch();
+    if (!bind(framebuffer)) return false;
+    const bool ok = submit_batch();
     auto prep = [&](TGAImage* img) -> std::uint8_t* {
         if (!img) return nullptr;
         if (img->width() != s.w || img->height() != s.h || image_bpp(*img) != 3) *img = TGAImage(s.w, s.h, TGAImage::RGB);
         return img->buffer();
     };
-    TRGL_SHIM_CHK(trgl_postprocess(s.ctx, nullptr, prep(zbuffer_image), prep(ao_map), prep(final_result)));
+    return TRGL_SHIM_OK(trgl_postprocess(s.ctx, nullptr, prep(zbuffer_image), prep(ao_map), prep(final_result))) && ok;
 }
 
 inline void print_render_stats() {                                                // our_gl.cpp:204-210
     trgl_shim::State& s = trgl_shim::state();
     trgl_stats st{};
-    if (s.ctx) { trgl_shim::submit_batch(); TRGL_SHIM_CHK(trgl_get_stats(s.ctx, &st)); }
+    if (s.ctx && (trgl_shim::submit_batch(), TRGL_SHIM_OK(trgl_get_stats(s.ctx, &st)))) { }
     else { st.min_x = st.min_y = INT32_MAX; st.max_x = st.max_y = INT32_MIN; st.min_z = std::numeric_limits<double>::infinity(); st.max_z = -st.min_z; }
     char line[1024];
     trgl_format_stats(&st, line, sizeof line);

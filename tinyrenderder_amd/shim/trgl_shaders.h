@@ -11,6 +11,15 @@ struct FlatShader : IShader {
     bool describe(trgl_shader_desc& d) const override { d.kind = TRGL_SHADER_FLAT; d.color = trgl_shim::pack_bgra(color); return true; }
 };
 
+// the shader that DISCARDS (our_gl.h:51: fragment() returns { true, ... } and rasterize() skips the fragment, our_gl.cpp:187-188):
+// a flat colour on the even cells of a cells x cells checker over the perspective-correct barycentrics (include/trgl.h)
+struct CheckerShader : IShader {
+    TGAColor color; int cells = 8;
+    bool describe(trgl_shader_desc& d) const override {
+        d.kind = TRGL_SHADER_CHECKER; d.color = trgl_shim::pack_bgra(color); d.uniforms.reserved = cells; return true;
+    }
+};
+
 // classic tinyrenderer Gouraud: per-vertex intensity, colour = base * intensity (TGAColor::operator*, tgaimage.h:55-62)
 struct GouraudShader : IShader {
     TGAColor base = TGAColor(255, 255, 255);
