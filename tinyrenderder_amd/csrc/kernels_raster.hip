@@ -340,8 +340,8 @@ struct BlockState {
     double pux, puy; uint32_t ptri;
     double puz, pruz, pz0, pz1, pz2;
     uint32_t pcd;           // ... and its colour (FLAT flushes) or `dl` (all others)
-    uint32_t frags; double zmin, zmax;
-    int x, y;
+    uint32_t frags; double zmax;   // z range of the fragments the lane wrote: the largest one is kept; the smallest IS the pixel's
+                                   // final depth (every write lowers it), read off at block-out
     us2 xy;                 // x | y << 16 as two 16-bit words (the bbox test of a visit is packed 16-bit arithmetic)
 #ifdef TRGL_DEBUG_COUNTERS
     unsigned long long dbg[16];    // work counters of the diagnostic build (profiles/raster_counters.py); [8] is summed over the lanes
@@ -407,14 +407,13 @@ __device__ __forceinline__ void resolve(BlockState& S, unsigned long long pend, 
             if (!discard) {
                 // :191-198, committed IN PLACE (asm operands tied to the state registers): written through ordinary assignments the
                 // compiler gives every state variable a second register inside the conditional resolve and copies all of them back at
-                // its end - nine moves per covered visit.  v_min / v_max give std::min / std::max up to the sign of a zero, which
-                // k_fold_stats settles from the first-zero keys below.
+                // its end - nine moves per covered visit.  v_max gives std::max up to the sign of a zero, which k_fold_stats settles
+                // from the first-zero keys below (as it does for the minimum, taken from the final depths at block-out).
                 asm volatile(
                     "v_mov_b64 %[sz], %[z]\n\t"                                                // :191
                     "v_add_u32 %[fr], 1, %[fr]\n\t"                                            // :194
-                    "v_min_f64 %[zmin], %[zmin], %[z]\n\t"                                     // :197
                     "v_max_f64 %[zmax], %[zmax], %[z]"                                           // :198
-                    : [sz] "+v"(S.z), [fr] "+v"(S.frags), [zmin] "+v"(S.zmin), [zmax] "+v"(S.zmax)
+                    : [sz] "+v"(S.z), [fr] "+v"(S.frags), [zmax] "+v"(S.zmax)
                     : [z] "v"(z));
                 if (KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE) {
                     asm volatile("v_mov_b32 %0, %1" : "+v"(S.id) : "v"(id));                    // (the colour comes from k_shade)
@@ -427,7 +426,8 @@ __device__ __forceinline__ void resolve(BlockState& S, unsigned long long pend, 
                 // std::min / std::max keep the first of equal values and +0.0 == -0.0: when the z range ends in a zero its sign is that
                 // of the first zero written in the reference's order (triangle, x, y), see DevStats
                 if (z == 0.0 && !zero_locked) {
-                    unsigned long long order = ((unsigned long long)S.ptri << 32) | ((unsigned long long)S.x << 16) | (unsigned long long)S.y;
+                    const uint32_t xy = __builtin_bit_cast(uint32_t, S.xy);
+                    unsigned long long order = ((unsigned long long)S.ptri << 32) | ((unsigned long long)(xy & 0xffffu) << 16) | (unsigned long long)(xy >> 16);
                     atomicMin(__builtin_signbit(z) ? &stats->zero_neg_key : &stats->zero_pos_key, order);
                 }
             }
@@ -542,11 +542,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
     const int X0 = px0 + 8 * w, Y0 = py0 + 8 * brow;
 
     BlockState S;
-    S.x = X0 + (lane & 7); S.y = Y0 + (lane >> 3);
-    S.xy = __builtin_bit_cast(us2, (uint32_t)S.x | ((uint32_t)S.y << 16));
-    const bool owned = S.x < fp.W && S.y < fp.H && S.y >= fp.strip_y0 && S.y < fp.strip_y1;
-    const size_t pix = (size_t)S.x + (size_t)S.y * fp.W;
-    S.pxc = (double)S.x + 0.5; S.pyc = (double)S.y + 0.5;
+    const int lx = X0 + (lane & 7), ly = Y0 + (lane >> 3);          // the lane's pixel
+    S.xy = __builtin_bit_cast(us2, (uint32_t)lx | ((uint32_t)ly << 16));
+    const bool owned = lx < fp.W && ly < fp.H && ly >= fp.strip_y0 && ly < fp.strip_y1;
+    const size_t pix = (size_t)lx + (size_t)ly * fp.W;
+    S.pxc = (double)lx + 0.5; S.pyc = (double)ly + 0.5;
     // Pixels of the block that this context does not own (rows outside the strip, beyond the image) hold -inf: no fragment
     // passes there, and they are not stored.
     S.z = -__builtin_inf();
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
     S.id = 0xffffffffu;
     S.pux = 0.0; S.puy = 0.0; S.ptri = 0;
     S.puz = -1.0; S.pruz = -1.0; S.pz0 = 0.0; S.pz1 = 0.0; S.pz2 = 0.0; S.pcd = 0;
-    S.frags = 0; S.zmin = __builtin_inf(); S.zmax = -__builtin_inf();
+    S.frags = 0; S.zmax = -__builtin_inf();
     const bool zero_locked = stats->zero_locked != 0;
 #ifdef TRGL_DEBUG_COUNTERS
     for (int k = 0; k < 16; ++k) S.dbg[k] = 0;
@@ -881,7 +881,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
     TRGL_STAMP(15);                // block out
     // ---- stats: our_gl.cpp:194-198, reduced per wave, then per workgroup: one partial per work item (k_fold_stats) ------
     uint32_t frags = S.frags;
-    unsigned long long kmin = zkey(S.zmin), kmax = zkey(S.zmax);
+    // (std::min over the written depths of a pixel is its last one: the z-test only lets smaller ones through)
+    unsigned long long kmin = zkey(S.frags ? S.z : __builtin_inf()), kmax = zkey(S.zmax);
     for (int o = 32; o; o >>= 1) {
         frags += __shfl_xor(frags, o);
         unsigned long long a = __shfl_xor(kmin, o); kmin = a < kmin ? a : kmin;
