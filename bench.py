@@ -3,8 +3,10 @@
 
 Workload (BASELINE.json configs[3], the one its metric "triangles/sec ... at 4096x4096" is quoted on):
 10 M synthetic random triangles, 4096x4096 RGB framebuffer + fp64 z-buffer, flat shader.
-A "step" is one full frame: clear -> setup -> stable tile binning -> LDS tile raster -> tile flush, with the
-triangle stream already resident in HBM when the timed region starts.
+A "step" is one full frame: clear -> setup -> stable tile binning -> block raster (one wavefront per 8x8 pixels, depths in
+registers) -> block-out, with the triangle stream already resident in HBM when the timed region starts.  The timed loop runs
+with the library's event profiling OFF (nothing waits inside it); a second, short loop with profiling on supplies the
+per-phase times and the k_raster launch duration of the roofline entry.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): strong scaling on the SAME frame — rank r owns
 framebuffer rows [r*H/N, (r+1)*H/N), every rank streams all triangles through setup (replicating 96 B/triangle of
@@ -139,6 +141,65 @@ def frames_in_flight(Context, W, H, kind, dclip, dcol, fb_expected, frames=20, d
             "frames_equal_timed_frame": same}
 
 
+def secondary_workload(name, dev, steps, warmup, check):
+    """BASELINE configs[1] / [2] (PHONG head stand-in at 2048^2 with the diffuse map / at 4096^2 with all three maps) as a
+    secondary record of the default line: frame time with profiling off, phases and the k_raster roofline entry from a profiled
+    loop, parity of the rendered frame against the C restatement (the PHONG body is restated from main.cpp's text)."""
+    import torch
+    from tinyrenderder_amd import scenes
+    from tinyrenderder_amd.api import Context, PHONG, make_uniforms, PHASE_RASTER, PHASE_SETUP, PHASE_BIN, PHASE_TOTAL, PHASE_RASTER_KERNEL
+    W = H = 2048 if name == "c2" else 4096
+    hd = scenes.head_standin(7, W, H)
+    d_, n_, s_ = scenes.procedural_textures(1024)
+    textures = {0: d_} if name == "c2" else {0: d_, 1: n_, 2: s_}
+    slots = (0, -1, -1) if name == "c2" else (0, 1, 2)
+    uniforms = make_uniforms(hd["model_view"], hd["key"], hd["fill"], hd["rim"], 1.0, *slots)
+    N = hd["clip"].shape[0]
+    dclip, dvary = torch.from_numpy(hd["clip"]).cuda(), torch.from_numpy(hd["varyings"]).cuda()
+    with Context(W, H, 3, device=dev) as ctx:
+        for slot, t in textures.items():
+            ctx.upload_texture(slot, t)
+
+        def step():
+            ctx.clear(); ctx.draw(PHONG, dclip, varyings=dvary, uniforms=uniforms, device=True); ctx.flush()
+        for _ in range(warmup):
+            step()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ctx.sync()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        ctx.set_profiling(True); ctx.reset_phase_ms()
+        for _ in range(max(3, steps // 4)):
+            step()
+        ph, nfl = ctx.phase_ms()
+        ctx.set_profiling(False)
+        raster_ms = ph[PHASE_RASTER_KERNEL] / max(nfl, 1)
+        algo = W * H * 11 + N * (96 + 8 * 24)
+        rec = {"workload": f"configs[{1 if name == 'c2' else 2}]: {N}-triangle head stand-in, {W}x{H}, PHONG, maps {sorted(textures)}",
+               "ms_per_step": ms, "triangles_per_s": N / (ms * 1e-3),
+               "phase_ms": {"setup": ph[PHASE_SETUP] / max(nfl, 1), "bin": ph[PHASE_BIN] / max(nfl, 1), "raster": ph[PHASE_RASTER] / max(nfl, 1),
+                            "raster_kernel": raster_ms, "flush_total": ph[PHASE_TOTAL] / max(nfl, 1)},
+               "roofline": {"bound": "hbm", "kernel": "k_raster<phong>", "achieved": algo / (raster_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": algo / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": raster_ms,
+                            "traffic": None}}
+        if check:
+            from oracle import orc
+            o = orc.Oracle(W, H, 3)
+            for slot, t in textures.items():
+                o.upload_texture(slot, t)
+            o.draw(orc.PHONG, hd["clip"], hd["varyings"], uniforms=orc.Uniforms.from_buffer_copy(bytes(uniforms)))
+            fb, z, line = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats_line()
+            ctx.reset_stats(); step()
+            line = ctx.stats_line()
+            rec["parity"] = {"checked": True, "fb": bool(np.array_equal(fb, o.fb)), "z": bool(np.array_equal(z.view(np.uint64), o.z.view(np.uint64))),
+                             "stats": bool(line == orc.format_stats_line(o.stats)),
+                             "against": ["oracle/trgl_oracle.c (C restatement; PHONG body restated from main.cpp text)"]}
+            rec["parity"]["ok"] = bool(rec["parity"]["fb"] and rec["parity"]["z"] and rec["parity"]["stats"])
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,6 +222,9 @@ def main():
                     help="nccl (= RCCL over xGMI, the measured configuration) or gloo: a rehearsal of the N > 1 code path with all ranks "
                          "on ONE GPU (a 1-GPU box cannot host two RCCL ranks); its numbers mean nothing")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL strip-gather path even with one rank (rehearsal)")
+    ap.add_argument("--secondary", default="c2,c3",
+                    help="secondary workloads appended to the default line as records (one GPU, default workload only; '' = none)")
+    ap.add_argument("--profile-steps", type=int, default=5, help="steps of the second, profiled loop (phase times, k_raster launch duration)")
     ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3"],
                     help="c4 (default, the metric's config): 10 M random flat triangles; c2/c3: PHONG head stand-in at 2048/4096")
     args = ap.parse_args()
@@ -252,8 +316,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ctx.set_profiling(True)
-    ctx.reset_phase_ms()
+    # the headline loop: event profiling OFF, so that no flush waits for the events of the one before it
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -263,7 +326,22 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # a second, short loop with profiling ON: HIP events on the context's stream around the phases and right around the k_raster launch
+    ctx.set_profiling(True)
+    ctx.reset_phase_ms()
+    tp0 = time.perf_counter()
+    for _ in range(max(args.profile_steps, 1)):
+        step()
+    fence()
+    elapsed_profiled = time.perf_counter() - tp0
     phase_ms, nfl = ctx.phase_ms()
+    rank_phases = None
+    if use_dist:      # every rank's phases, for the record of the multi-GPU run
+        mine = torch.tensor([phase_ms[PHASE_SETUP], phase_ms[PHASE_BIN], phase_ms[PHASE_RASTER], phase_ms[PHASE_RASTER_KERNEL], phase_ms[PHASE_TOTAL]],
+                            dtype=torch.float64, device="cuda") / max(nfl, 1)
+        allp = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        rank_phases = [dict(zip(("setup", "bin", "raster", "raster_kernel", "flush_total"), [float(v) for v in p.cpu()])) for p in allp]
     info = ctx.last_flush_info()
     fb_timed = ctx.read_framebuffer() if (rank == 0 and world == 1 and not args.no_parity) else None     # the last timed frame
     # frame write-out alone (outside the timed region): clear + flush with no triangles = k_raster storing W*H*(8+bpp)
@@ -340,12 +418,14 @@ def main():
         out = {
             "metric": "triangles/sec (+ Mpixels/sec) at 4096x4096; achieved HBM GB/s vs peak",
             "value": None if failed else tri_per_s, "unit": "triangles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "ms_per_step_profiled": elapsed_profiled * 1e3 / max(args.profile_steps, 1),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl_name,
                        "width": W, "height": H, "triangles": N, "tile": 32,
                        "parallelism": (f"screen strips x{world}" if args.partition == "strips" else f"interleaved {args.band_rows}-row bands x{world}")
                                       + (" + RCCL all-gather of colour strips" if world > 1 else "")},
+            "rccl_ranks": (dist.get_world_size() if (use_dist and args.backend == "nccl") else 0),
             "parity": parity,
             "mpixels_per_s": W * H * args.steps / elapsed / 1e6,
             "tri_tile_pairs": info["pairs"],
@@ -356,20 +436,27 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": raster_ms},
         }
-        # the two streaming phases next to the raster kernel, as bytes moved per second (HIP-event phase times):
-        # k_setup reads 96 B of vertices + 4 B of colour and writes a 128-B record + 12 B per triangle; binning moves
-        # 36 B per pair with 16-bit tile keys (expand 6, two histogram reads 4, two scatter passes 24, bounds 2; 52 B with the 32-bit
-        # keys of frames beyond 65536 tiles) + 12 B per triangle
+        # the two streaming phases next to the raster kernel, as bytes moved per second (HIP-event phase times), on the bytes the
+        # IMPLEMENTATION moves and on SURVEY.md section 8(d)'s ALGORITHMIC bytes:
+        # k_setup reads 96 B of vertices + 4 B of colour and writes a 128-B record + 12 B per triangle (algorithmic: the 100 B read);
+        # binning moves 46 B per pair with 16-bit tile keys - a pair is (tile 2 B, triangle 4 B, 4x4 block mask 2 B): expand writes 8, two
+        # histogram reads 4, two scatter passes 32, bounds 2 (62 B with the 32-bit keys of frames beyond 65536 tiles) - + 12 B per
+        # triangle (algorithmic: one 4-B list entry per pair written once and read once by the raster)
         setup_ms = phase_ms[PHASE_SETUP] / max(nfl, 1)
         bin_ms = phase_ms[PHASE_BIN] / max(nfl, 1)
         if kind == FLAT and setup_ms > 0 and bin_ms > 0:
             setup_bytes = N * (96 + 4 + 12) + (N / world) * 128
-            bin_bytes = info["pairs"] * (36 if ((W + 31) // 32) * ((H + 31) // 32) <= 65536 else 52) + N * 12
+            bin_bytes = info["pairs"] * (46 if ((W + 31) // 32) * ((H + 31) // 32) <= 65536 else 62) + N * 12
+            gbs = lambda b, ms: b / (ms * 1e-3) / 1e9
             out["streaming_phases"] = {
-                "k_setup": {"bytes": setup_bytes, "ms": setup_ms, "achieved": setup_bytes / (setup_ms * 1e-3) / 1e9,
-                            "unit": "GB/s", "frac": setup_bytes / (setup_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                "binning": {"bytes": bin_bytes, "ms": bin_ms, "achieved": bin_bytes / (bin_ms * 1e-3) / 1e9,
-                            "unit": "GB/s", "frac": bin_bytes / (bin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                "k_setup": {"bytes": setup_bytes, "ms": setup_ms, "achieved": gbs(setup_bytes, setup_ms), "unit": "GB/s",
+                            "frac": gbs(setup_bytes, setup_ms) / HBM_PEAK_GBS, "algorithmic_bytes": N * 100,
+                            "algorithmic_frac": gbs(N * 100, setup_ms) / HBM_PEAK_GBS},
+                "binning": {"bytes": bin_bytes, "ms": bin_ms, "achieved": gbs(bin_bytes, bin_ms), "unit": "GB/s",
+                            "frac": gbs(bin_bytes, bin_ms) / HBM_PEAK_GBS, "algorithmic_bytes": info["pairs"] * 8,
+                            "algorithmic_frac": gbs(info["pairs"] * 8, bin_ms) / HBM_PEAK_GBS}}
+        if rank_phases:
+            out["rank_phase_ms"] = rank_phases
         if writeout:
             out["writeout"] = writeout
         if write_path:
@@ -380,6 +467,8 @@ def main():
             out["frames_in_flight"] = inflight
         if cpu:
             out["cpu_baseline"] = cpu
+        if world == 1 and args.workload == "c4" and args.secondary:
+            out["secondary"] = [secondary_workload(nm, dev, 40, 5, check=not args.no_parity and args.cpu_sample > 0) for nm in args.secondary.split(",") if nm]
         print(json.dumps(out))
         if failed:
             print("PARITY FAILURE: the GPU frame differs from the reference's; no throughput is reported", file=sys.stderr)

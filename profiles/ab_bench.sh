@@ -5,7 +5,7 @@ TAG=$1; shift
 mkdir -p gpurun_out
 for L in "$@"; do
   n=$(basename $L .so)
-  TRGL_LIB=$PWD/$L python3 bench.py --cpu-sample 0 --end-to-end-frames 0 --writeout-frames 0 --frames-in-flight 1 > gpurun_out/ab_${TAG}_$n.json 2> gpurun_out/ab_${TAG}_$n.err
+  TRGL_LIB=$PWD/$L python3 bench.py --secondary= --cpu-sample 0 --end-to-end-frames 0 --writeout-frames 0 --frames-in-flight 1 > gpurun_out/ab_${TAG}_$n.json 2> gpurun_out/ab_${TAG}_$n.err
   python3 - <<PY
 import json
 try:

@@ -4,7 +4,7 @@ set -e
 OUT=gpurun_out/pmc_raster_${1:-x}
 rm -rf $OUT
 mkdir -p $OUT; export TMPDIR=/tmp
-ARGS="bench.py --steps 3 --warmup 1 --cpu-sample 0 --writeout-frames 0 --no-parity --end-to-end-frames 0"
+ARGS="bench.py --secondary= --steps 3 --warmup 1 --cpu-sample 0 --writeout-frames 0 --no-parity --end-to-end-frames 0"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_BRANCH --output-format csv -d $OUT/a -- python3 $ARGS > $OUT/a.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU SQ_IFETCH --output-format csv -d $OUT/b -- python3 $ARGS > $OUT/b.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_WAVES SQ_LEVEL_WAVES SQ_INST_CYCLES_SALU --output-format csv -d $OUT/c -- python3 $ARGS > $OUT/c.log 2>&1

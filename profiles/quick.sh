@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick A/B on the GPU box: bench line (phases only) + work counters of the diagnostic build
-ARGS="--cpu-sample 0 --writeout-frames 0 --end-to-end-frames 0 --steps 20 --warmup 3"
+ARGS="--secondary= --cpu-sample 0 --writeout-frames 0 --end-to-end-frames 0 --steps 20 --warmup 3"
 python3 bench.py $ARGS "$@" 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])

@@ -12,10 +12,10 @@ out = sys.argv[1]
 def short(name):
     m = re.search(r"k_raster<(\d)(?:, (\d))?(?:, (true|false))?>", name)
     if m:
-        return "k_raster<" + ["flat", "gouraud", "phong", "eye", "any"][int(m.group(1))] + (", bpp " + m.group(2) if m.group(2) and m.group(2) != "0" else "") + (", all well scaled" if m.group(3) == "true" else "") + ">"
+        return "k_raster<" + ["flat", "gouraud", "phong", "eye", "checker", "any"][int(m.group(1))] + (", bpp " + m.group(2) if m.group(2) and m.group(2) != "0" else "") + (", all well scaled" if m.group(3) == "true" else "") + ">"
     m = re.search(r"k_shade<(\d)>", name)
     if m:
-        return "k_shade<" + ["flat", "gouraud", "phong", "eye", "any"][int(m.group(1))] + ">"
+        return "k_shade<" + ["flat", "gouraud", "phong", "eye", "checker", "any"][int(m.group(1))] + ">"
     for k in ("k_setup", "k_chunk_spine", "k_radix_scan_rows", "k_expand", "k_radix_hist", "k_radix_scatter",
               "k_bounds", "k_make_items", "k_fold_stats", "k_selftest_division"):
         if k in name:

@@ -3,7 +3,7 @@
 set -e
 OUT=gpurun_out/trace_${1:-x}
 rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --cpu-sample 0 --writeout-frames 0 --no-parity --end-to-end-frames 0 --frames-in-flight 1 > $OUT/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --secondary= --cpu-sample 0 --writeout-frames 0 --no-parity --end-to-end-frames 0 --frames-in-flight 1 > $OUT/bench_trace.log 2>&1
 python3 - <<PY
 import csv, glob, re
 from collections import defaultdict

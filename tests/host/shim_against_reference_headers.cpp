@@ -11,8 +11,10 @@ int main() {
     for (int v = 0; v < 3; ++v) clip[v] = sh.vertex(0, v);
     rasterize(clip, sh, framebuffer);
     std::vector<double> saved = zbuffer; zbuffer = saved;
+    double d = zbuffer[5]; zbuffer[6] = d + 1.0; zbuffer[7] = zbuffer[6];       // main.cpp:759-style element reads, and writes
+    CheckerShader chk; chk.color = TGAColor(1, 2, 3); rasterize(clip, chk, framebuffer);
     gl_draw_model(m, sh, framebuffer);
-    gl_flush(framebuffer);
+    if (!gl_flush(framebuffer)) return gl_last_error();
     print_render_stats();
     return 0;
 }

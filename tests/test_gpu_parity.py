@@ -418,11 +418,12 @@ def test_bench_rccl_strip_gather_path_single_rank():
     import sys
     root = os.path.dirname(HERE)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1",
-                        "--triangles", "300000", "--size", "1024", "--cpu-sample", "0"], capture_output=True, text=True, timeout=600)
+                        "--triangles", "300000", "--size", "1024", "--cpu-sample", "0", "--secondary="], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert d["rccl_ranks"] == 1 and len(d["rank_phase_ms"]) == 1 and d["rank_phase_ms"][0]["raster_kernel"] > 0     # what the driver's SCALE record can be checked against
 
 
 @pytest.mark.parametrize("cfg", ["c2_2048_phong_diffuse", "c3_4096_phong_diffuse_normal_spec"])
@@ -848,3 +849,25 @@ def test_c_abi_gather_single_rank_communicator(partition):
     finally:
         api.rccl_comm_destroy(comm)
     assert np.array_equal(z.view(np.uint64), oz.view(np.uint64)) and np.array_equal(fb, ofb) and st == ost
+
+
+def test_interleaved_rank_without_rows_draws_nothing_and_stays_usable():
+    """trgl_set_interleave with more ranks x band rows than the image has rows: a rank whose bands lie beyond the image owns no tile
+    row.  Its flushes must complete (no launch over an empty grid, no stuck draw list), count nothing, and the context must keep
+    working when it is given rows again."""
+    W, H = 96, 64
+    clip, col = scenes.random_triangles(500, W, H, seed=3, rmin=2, rmax=24)
+    with Context(W, H, 3) as ctx:
+        ctx.set_interleave(32, 3, 4)                 # bands of 32 rows, 4 ranks: ranks 2 and 3 own nothing of 64 rows
+        ctx.draw(FLAT, clip, colors=col)
+        st = ctx.stats()
+        assert st[0] == 500 and st[1] == 0
+        ctx.draw(FLAT, clip, colors=col)             # a second flush on the same context
+        assert ctx.stats()[1] == 0
+        ctx.set_strip(0, H)
+        ctx.reset_stats(); ctx.clear()
+        ctx.draw(FLAT, clip, colors=col)
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    o = orc.Oracle(W, H, 3)
+    o.draw(orc.FLAT, clip, colors=col)
+    assert np.array_equal(fb, o.fb) and np.array_equal(z.view(np.uint64), o.z.view(np.uint64)) and st == o.stats

@@ -96,6 +96,22 @@ def test_gpu_postprocess_matches_restatement(name):
 
 
 @pytest.mark.gpu
+def test_gpu_postprocess_odd_size():
+    """W * H not a multiple of 4 (33 x 31): the three output images sit at 16-byte boundaries of the device buffer, so the dword
+    stores of the z-image and composite kernels stay aligned whatever the size."""
+    from tinyrenderder_amd.api import Context, FLAT
+    W, H = 33, 31
+    clip, col = scenes.random_triangles(400, W, H, seed=77, rmin=2, rmax=16)
+    with Context(W, H, 3) as ctx:
+        ctx.draw(FLAT, clip, colors=col)
+        fb, z = ctx.read_framebuffer(), ctx.read_zbuffer()
+        out = ctx.postprocess()
+    ao = orc.ssao(z)
+    assert np.array_equal(out["zbuffer_image"], orc.zbuffer_image(z))
+    assert np.array_equal(out["ao"], ao) and np.array_equal(out["final"], orc.composite(fb, ao))
+
+
+@pytest.mark.gpu
 def test_gpu_postprocess_4096():
     """Full-size post-process on the C4 frame (1 M-triangle prefix): SSAO reads 64 depths per pixel from LDS tiles."""
     from tinyrenderder_amd.api import Context, FLAT

@@ -617,7 +617,7 @@ void launch_expand(hipStream_t s, const FrameParams& fp, uint32_t first, uint32_
                            blk_base, tilebox, (uint32_t*)keys, vals, bmask, pairs_total, cap);
 }
 
-uint32_t radix_num_workers(uint32_t P) { return (P + RADIX_CHUNK - 1) / RADIX_CHUNK; }   // = blocks of a pass
+uint32_t radix_num_workers(uint32_t P) { return (uint32_t)(((uint64_t)P + RADIX_CHUNK - 1) / RADIX_CHUNK); }   // = blocks of a pass
 
 // The pair count of the flush stays on the device (`pairs_total`): grids cover `cap`, the capacity of the pair buffers,
 // and blocks past the last pair do nothing, so the host never has to wait for the count before it can queue these.
@@ -642,8 +642,8 @@ void launch_radix_pass(hipStream_t s, const void* keys_in, const uint32_t* vals_
 void launch_bounds(hipStream_t s, const void* keys, bool key16, const unsigned long long* pairs_total, uint32_t cap,
                    uint32_t* tile_start, uint32_t* tile_end) {
     if (!cap) return;
-    if (key16) hipLaunchKernelGGL(k_bounds<uint16_t>, dim3((cap + 1023) / 1024), dim3(256), 0, s, (const uint16_t*)keys, pairs_total, cap, tile_start, tile_end);
-    else hipLaunchKernelGGL(k_bounds<uint32_t>, dim3((cap + 1023) / 1024), dim3(256), 0, s, (const uint32_t*)keys, pairs_total, cap, tile_start, tile_end);
+    if (key16) hipLaunchKernelGGL(k_bounds<uint16_t>, dim3((unsigned)(((uint64_t)cap + 1023) / 1024)), dim3(256), 0, s, (const uint16_t*)keys, pairs_total, cap, tile_start, tile_end);
+    else hipLaunchKernelGGL(k_bounds<uint32_t>, dim3((unsigned)(((uint64_t)cap + 1023) / 1024)), dim3(256), 0, s, (const uint32_t*)keys, pairs_total, cap, tile_start, tile_end);
 }
 
 }  // namespace trgl

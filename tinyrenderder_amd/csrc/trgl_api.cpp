@@ -386,10 +386,12 @@ int trgl_postprocess(trgl_ctx* c, const trgl_ssao_params* params, uint8_t* zimg,
         return fail(c, TRGL_E_INVALID, "trgl_postprocess: 1..16 directions, >= 1 step");
     int r = flush_sync(c); if (r) return r;
     const size_t npx = (size_t)c->W * c->H;
-    if ((r = grow(c, c->pp_out, c->cap_pp, npx * 9 + 64))) return r;      // allocated once per context, not per call
+    // three [H][W][3] images, each at a 16-byte boundary (the kernels store dwords: W * H need not be a multiple of 4), then the keys
+    const size_t img = (npx * 3 + 15) & ~size_t(15);
+    if ((r = grow(c, c->pp_out, c->cap_pp, img * 3 + 64))) return r;      // allocated once per context, not per call
     uint8_t* d_out = c->pp_out;
-    unsigned long long* d_keys = reinterpret_cast<unsigned long long*>(d_out + ((npx * 9 + 15) & ~size_t(15)));
-    uint8_t* d_z = d_out; uint8_t* d_ao = d_out + npx * 3; uint8_t* d_fin = d_out + npx * 6;
+    unsigned long long* d_keys = reinterpret_cast<unsigned long long*>(d_out + img * 3);
+    uint8_t* d_z = d_out; uint8_t* d_ao = d_out + img; uint8_t* d_fin = d_out + img * 2;
     hipStream_t s = c->stream;
     if (zimg) launch_zimage(s, c->zb, c->W, c->H, d_keys, d_z);
     if (ao || fin) {
@@ -466,7 +468,7 @@ static int queue_binning(trgl_ctx* c, const FrameParams& fp, uint32_t cap, int* 
 static int grow_pairs(trgl_ctx* c, size_t need) {
     if (need <= c->cap_pairs) return TRGL_OK;
     size_t ncap = (need + need / 4 + 1024 + 3) & ~size_t(3);     // a multiple of 4 entries: k_bounds reads 16 bytes at a time
-    if (ncap > 0xfffffff0ull) ncap = 0xfffffff0ull;
+    if (ncap > 0xffffe000ull) ncap = 0xffffe000ull;        // (grids are sized by cap + 4095 in 32 bits; a flush of 2^32 - 16 pairs and more is refused)
     int r;
     for (int k = 0; k < 2; ++k) {
         if ((r = realloc_dev(c, (void**)&c->keys[k], ncap * 4))) return r;
@@ -574,7 +576,7 @@ int trgl_flush_end(trgl_ctx* c) {
         // the pair count was copied to pinned memory right after k_setup; the GPU is busy with the binning queued behind it
         HIPCHK(c, hipEventSynchronize(c->ev_pairs));
         const unsigned long long P64 = c->stats_pinned->pairs_total;
-        if (P64 > 0xfffffff0ull) {
+        if (P64 > 0xffffe000ull) {
             c->draws.clear(); c->queued_tris = 0;          // nothing of this flush was drawn (every binning kernel saw the overflow)
             return fail(c, TRGL_E_UNSUPPORTED, "flush: more than 2^32 triangle-tile pairs; submit in smaller batches");
         }

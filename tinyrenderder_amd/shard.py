@@ -101,6 +101,10 @@ class StripLoop:
     the previous frame's pixels until the next gather lands."""
 
     def __init__(self, ctx, gather):
+        # The gather is ordered against the RASTER through torch's current stream (a collective's wait() orders streams, it does
+        # not block the host), so the context has to enqueue on that stream, not on the non-blocking stream it was created with.
+        import torch
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         self.ctx, self.gather, self.pending = ctx, gather, None
 
     def step(self, submit):

@@ -66,13 +66,23 @@ public:
     operator const std::vector<double>&() const { pull(); return host_; }
     trgl_zbuffer_proxy& operator=(const std::vector<double>& v) { pull(); host_ = v; touched(); return *this; }
     double operator[](std::size_t i) const { pull(); return host_[i]; }
-    double& operator[](std::size_t i) { pull(); touched(); return host_[i]; }
+    // `zbuffer[i]` on the (non-const) global: reading it must not mark the host copy as modified - that would upload all W * H
+    // depths again before the next draw - so the element comes back as a small reference object that marks on ASSIGNMENT only
+    class element {
+        trgl_zbuffer_proxy& z_; std::size_t i_;
+    public:
+        element(trgl_zbuffer_proxy& z, std::size_t i) : z_(z), i_(i) {}
+        operator double() const { z_.pull(); return z_.host_[i_]; }
+        element& operator=(double v) { z_.pull(); z_.host_[i_] = v; z_.touched(); return *this; }
+        element& operator=(const element& o) { return *this = double(o); }
+    };
+    element operator[](std::size_t i) { return element(*this, i); }
     std::size_t size() const { return host_.size(); }
     bool empty() const { return host_.empty(); }
     const double* data() const { pull(); return host_.data(); }
     double* data() { pull(); touched(); return host_.data(); }
     std::vector<double>::const_iterator begin() const { pull(); return host_.begin(); }
-    std::vector<double>::const_iterator end() const { return host_.end(); }
+    std::vector<double>::const_iterator end() const { pull(); return host_.end(); }     // (begin() and end() may be evaluated in either order)
     void assign(std::size_t n, double v);    // init_zbuffer (our_gl.cpp:72-74)
     void resize(std::size_t n) { host_.resize(n); }
     std::vector<double>& raw() { return host_; }   // the shim's own access: no synchronisation
