@@ -125,6 +125,18 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
                 const double dl[4] = { r.s0x, r.s0y, r.s1x, r.s1y };
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ws = ws && (dl[q] == 0.0 || fabs(dl[q]) >= SMALL);
+                // ... and not a sliver whose coverage roundings could reach past its bounding box.  k_raster's fast visit does not test
+                // a pixel against the bbox of :130-133: with every computed u within E = 2^-50 S R of its exact value (S = sum of the
+                // |edge deltas|, R >= |A - pixel centre| (L1) on the blocks the bbox touches) and u.z within 2^-52 S^2, a pixel that
+                // passes the sign test has exact barycentrics >= -eps, eps < 2^-48 S R / |u.z|, so it lies within 2 eps S of the
+                // triangle's extent in x and in y - while a pixel centre outside floor(min) .. ceil(max) is at least 0.5 away from it.
+                // 2^-40 S^2 R < |u.z| (R >= S) makes 2 eps S < 2^-7.  The others take the literal path, which tests the bbox.
+                {
+                    const double S = (fabs(r.s0x) + fabs(r.s0y)) + (fabs(r.s1x) + fabs(r.s1y));
+                    const double rx = fmax(fabs(r.ax - ((double)bx0 + 0.5)), fabs(r.ax - ((double)bx1 + 0.5)));
+                    const double ry = fmax(fabs(r.ay - ((double)by0 + 0.5)), fabs(r.ay - ((double)by1 + 0.5)));
+                    ws = ws && 0x1p-40 * (S * S) * (rx + ry + 17.0 + S) < fabs(r.uz);
+                }
                 r.ruz = ws ? 1.0 / r.uz : 0.0;
             }
             r.z0 = ndc[2]; r.z1 = ndc[6]; r.z2 = ndc[10];

@@ -306,12 +306,14 @@ constexpr int RING = 512;                           // candidate ring of a wave 
 typedef const __attribute__((address_space(4))) TriRec CRec;      // records through the scalar cache
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
-// The scan constants of one triangle, wave-uniform (SGPRs): chunks 0-5 of its record.
+// The scan constants of one triangle, wave-uniform (SGPRs): its whole record, two scalar loads of 64 B.
 struct TriScan {
     double ax, ay, s0x, s0y, s1x, s1y, c0, uz, g1, g2;
     uint32_t bx, by;      // as stored: bx0 | by0 << 16, bx1 | by1 << 16
     uint32_t color, dl;
     double ruz, z0, z1, z2;       // ride along for the lanes that note a fragment (see BlockState)
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    u32x16 lo, hi;                // the 32 registers as requested: all of them stay allocated until scan_wait()
 };
 __device__ __forceinline__ TriScan load_scan(const TriRec* __restrict__ recs, uint32_t tri) {
     TriScan T;
@@ -319,15 +321,24 @@ __device__ __forceinline__ TriScan load_scan(const TriRec* __restrict__ recs, ui
     tri &= 63u;          // timing experiment only (wrong frames): every visit reads one of 64 records = scalar-cache hits
 #endif
 #if __HIP_DEVICE_COMPILE__
-    CRec* r = (CRec*)(recs + tri);
-    T.ax = r->ax; T.ay = r->ay; T.s0x = r->s0x; T.s0y = r->s0y; T.s1x = r->s1x; T.s1y = r->s1y; T.c0 = r->c0; T.uz = r->uz;
-    T.g1 = r->g1; T.g2 = r->g2;
-    const __attribute__((address_space(4))) uint32_t* q = (const __attribute__((address_space(4))) uint32_t*)r + 20;
-    T.bx = q[0]; T.by = q[1]; T.color = q[2]; T.dl = q[3];
-    T.ruz = r->ruz; T.z0 = r->z0; T.z1 = r->z1; T.z2 = r->z2;
+    // (a flush holds at most TRGL_FLUSH_MAX_TRIS = 2^25 records: the byte offset fits the 32-bit scalar offset of s_load)
+    // The record as TWO requests of 16 dwords, written out: from C++ the second half becomes three (8 + 4 + 2 dwords around the bbox,
+    // which the fast visit does not use).  The compiler does not know that these registers arrive later: every use is preceded by
+    // scan_wait() below, and nothing else may touch them in between (the two sets A and B of the visit loop are never copied).
+    TriScan::u32x16 g, h;
+    asm volatile("s_load_dwordx16 %0, %2, %3 offset:0x0\n\ts_load_dwordx16 %1, %2, %3 offset:0x40" : "=&s"(g), "=&s"(h) : "s"(recs), "s"(tri << 7));
+    T.lo = g; T.hi = h;
+    auto dg = [&](int i) { return __builtin_bit_cast(double, ((unsigned long long)g[i + 1] << 32) | g[i]); };
+    auto dh = [&](int i) { return __builtin_bit_cast(double, ((unsigned long long)h[i + 1] << 32) | h[i]); };
+    T.ax = dg(0); T.ay = dg(2); T.s0x = dg(4); T.s0y = dg(6); T.s1x = dg(8); T.s1y = dg(10); T.c0 = dg(12); T.uz = dg(14);
+    T.g1 = dh(0); T.g2 = dh(2); T.ruz = dh(4); T.z0 = dh(6); T.z1 = dh(8); T.z2 = dh(10);
+    T.bx = h[12]; T.by = h[13]; T.color = h[14]; T.dl = h[15];
 #endif
     return T;
 }
+// (the registers of a set are inputs of the wait: a field that the kernel variant never reads - the bbox, colour or `dl` - would otherwise
+// be dead from the start, and its register handed to something else while the load that writes it is still in flight)
+__device__ __forceinline__ void scan_wait(const TriScan& T) { asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(T.lo), "s"(T.hi) : "memory"); }
 
 // Per-wave state: the block's pixels (one per lane) and the running statistics of our_gl.cpp:194-198.
 struct BlockState {
@@ -571,47 +582,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
     // step are requested before the candidates of this one are processed.  Loads without a branch around them (clamped index, masks
     // cleared outside [beg, end)), so that the wait for THIS step's entries can leave the next step's loads in flight.
     const uint32_t p_first = beg & ~3u;
-    auto load_step = [&](uint32_t p0, uint4& tri4, uint32_t& cand4) {
+    auto load_step = [&](uint32_t p0, uint4& tri4, uint2& m) {
         const uint32_t pl = p0 + 4u * (uint32_t)lane, p = min(pl, (end - 1u) & ~3u);
         tri4 = *reinterpret_cast<const uint4*>(vals + p);
-        const uint2 m = *reinterpret_cast<const uint2*>(bmask + p);
-        // bit j: entry pl + j is in [beg, end) and its bbox reaches this wave's block
-        uint32_t c = ((m.x >> kblk) & 1u) | (((m.x >> (16 + kblk)) & 1u) << 1) | (((m.y >> kblk) & 1u) << 2) | (((m.y >> (16 + kblk)) & 1u) << 3);
-        // valid entries of the lane: [lo, hi).  (Written without a wrapping subtraction under a select: in the first step of a list
-        // `pl < end ? min(end - pl, 4) : 0` reached the ISA as a saturating 4 - (end - pl), which takes every lane PAST the end for fully
-        // valid - lists shorter than a step then appended whatever followed them in the pair buffer, stale words of an earlier flush
-        // included; profiles/one_case.py with the diagnostic build found it.)
-        const uint32_t lo = min(beg - min(pl, beg), 4u), hi = min(end - min(pl, end), 4u);
-        c &= (0xfu << lo) & (0xfu >> (4u - hi));
-        cand4 = c;
+        m = *reinterpret_cast<const uint2*>(bmask + p);
     };
-    uint4 tri_n = make_uint4(0, 0, 0, 0); uint32_t cand_n = 0;
-    if (beg < end) load_step(p_first, tri_n, cand_n);
+    uint4 tri_n = make_uint4(0, 0, 0, 0); uint2 m_n = make_uint2(0, 0);
+    if (beg < end) load_step(p_first, tri_n, m_n);
     for (uint32_t p0 = p_first; p0 < end; p0 += 256) {
-        const uint4 tri_c = tri_n; const uint32_t cand_c = cand_n;
+        const uint4 tri_c = tri_n; const uint2 m_c = m_n;
         TRGL_STAMP(10);            // startup (first step) / whatever is left between the stamps below
-        load_step(p0 + 256, tri_n, cand_n);               // (past the end: clamped index, no candidates)
+        load_step(p0 + 256, tri_n, m_n);                  // (past the end: clamped index; its entries are never looked at)
         // append the step's candidates to the ring in list order: entry 4 l + j comes after every entry of the lanes below l
         {
-            const unsigned long long b0 = __ballot(cand_c & 1u), b1 = __ballot(cand_c & 2u), b2 = __ballot(cand_c & 4u), b3 = __ballot(cand_c & 8u);
+            // c_j: entry 4 l + j of the step reaches this wave's block (bit kblk of its mask) ...
+            uint32_t c0 = (m_c.x >> kblk) & 1u, c1 = (m_c.x >> (16 + kblk)) & 1u, c2 = (m_c.y >> kblk) & 1u, c3 = (m_c.y >> (16 + kblk)) & 1u;
+            if (p0 < beg || p0 + 256u > end) {
+                // ... and lies in [beg, end): only the first and the last step of a list hold entries that do not.  Valid entries of
+                // the lane: [lo, hi).  (Written without a wrapping subtraction under a select: `pl < end ? min(end - pl, 4) : 0` reached
+                // the ISA as a saturating 4 - (end - pl), which takes every lane PAST the end for fully valid - lists shorter than a
+                // step then appended whatever followed them in the pair buffer, stale words of an earlier flush included;
+                // profiles/one_case.py with the diagnostic build found it.)
+                const uint32_t pl = p0 + 4u * (uint32_t)lane;
+                const uint32_t lo = min(beg - min(pl, beg), 4u), hi = min(end - min(pl, end), 4u);
+                const uint32_t v = (0xfu << lo) & (0xfu >> (4u - hi));
+                c0 &= v; c1 &= v >> 1; c2 &= v >> 2; c3 &= v >> 3;
+            }
+            const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1), b2 = __ballot(c2), b3 = __ballot(c3);
             if (b0 | b1 | b2 | b3) {
                 uint32_t pos = head + cnt;
                 pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u));
                 pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
                 pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
                 pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, 0u));
-                if (cand_c & 1u) ring[pos & (RING - 1)] = tri_c.x;
-                pos += cand_c & 1u;
-                if (cand_c & 2u) ring[pos & (RING - 1)] = tri_c.y;
-                pos += (cand_c >> 1) & 1u;
-                if (cand_c & 4u) ring[pos & (RING - 1)] = tri_c.z;
-                pos += (cand_c >> 2) & 1u;
-                if (cand_c & 8u) ring[pos & (RING - 1)] = tri_c.w;
+                if (c0) ring[pos & (RING - 1)] = tri_c.x;
+                pos += c0;
+                if (c1) ring[pos & (RING - 1)] = tri_c.y;
+                pos += c1;
+                if (c2) ring[pos & (RING - 1)] = tri_c.z;
+                pos += c2;
+                if (c3) ring[pos & (RING - 1)] = tri_c.w;
 #ifdef TRGL_DEBUG_COUNTERS
                 {   // a candidate that is no triangle of the flush: remember where the first one came from
                     const uint32_t trs[4] = { tri_c.x, tri_c.y, tri_c.z, tri_c.w };
+                    const uint32_t cs[4] = { c0, c1, c2, c3 };
                     for (int j = 0; j < 4; ++j)
-                        if (((cand_c >> j) & 1u) && trs[j] >= fp.n_tris && atomicCAS(&stats->dbg[10], 0ull, 1ull) == 0ull) {
+                        if (cs[j] && trs[j] >= fp.n_tris && atomicCAS(&stats->dbg[10], 0ull, 1ull) == 0ull) {
                             stats->dbg[11] = ((unsigned long long)(p0 + 4u * (uint32_t)lane + (uint32_t)j) << 32) | trs[j];
                             stats->dbg[12] = ((unsigned long long)beg << 32) | end;
                             stats->dbg[13] = ((unsigned long long)(uint32_t)t << 32) | (uint32_t)kblk;
@@ -643,7 +659,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
             if (keep) {
                 const double2* q = reinterpret_cast<const double2*>(recs + tri);
                 const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
-                const uint4 q5 = reinterpret_cast<const uint4*>(q)[5];
+                const uint4 q5 = reinterpret_cast<const uint4*>(q)[7];
                 if (ALLWS || !(q5.w & TRGL_DL_LITERAL)) {
                     const double ax = q0.x, ay = q0.y, s0x = q1.x, s0y = q1.y, s1x = q2.x, s1y = q2.y, c0 = q3.x, uz = q3.y, g1 = q4.x, g2 = q4.y;
                     // pixel centres of (bbox n block): [xlo, xhi] x [ylo, yhi]
@@ -709,8 +725,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                     // save / restore pairs and a mask -> vector -> mask round trip for the ballot: ~30 vector + ~25 scalar.)  Every
                     // vector instruction issues for all 64 lanes whether they matter or not, so nothing is masked: lanes outside
                     // (bbox n block), hidden lanes and uncovered lanes only drop out of the final mask.
-                    //   lanes of (bbox n block): x | y << 16 against the bbox as packed 16-bit words - both halves of (xy - lo) <= (hi - lo)
-                    //     (the subtraction of a half that lies below `lo` wraps to a large value)
+                    //   NO test of the lane's pixel against the triangle's bbox (our_gl.cpp:130-133 only visits bbox pixels): a pixel centre
+                    //     outside floor(min) .. ceil(max) is at least half a pixel away from the triangle, and k_setup sends every triangle
+                    //     for which the roundings of u could bridge that (2^-40 S^2 R >= |u.z|) down the literal path below, which keeps the
+                    //     test.  Pixels beyond the image or outside the strip hold -inf and fail the depth comparison.
                     //   barycentric(), our_gl.cpp:77-86: s0z = ax - x, s1z = ay - y (s0.xy, s1.xy and u.z hoisted into the record)
                     //   depth first: zpl = fma(s0z, g1, fma(s1z, g2, c0)); a pixel with zpl >= its stored depth fails the z-test whatever
                     //     its coverage (k_setup); NaN reads as keep.  No lane left: the visit ends here.
@@ -719,21 +737,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                     //   covered <=> !(us < u.z) && !(u.y > 0) && !(u.x > 0): u.z < 0 and nothing can over/underflow, so the signs of the
                     //     quotients of :85 are known without dividing ("exactness"); max(u.x, u.y) > 0 <=> one of them is.
                     double s0z, s1z, ta, tb2;
-                    uint32_t tt;
+#ifdef TRGL_DEBUG_COUNTERS
+                    am = __ballot(__builtin_bit_cast(uint32_t, __builtin_elementwise_max(S.xy - __builtin_bit_cast(us2, T.bx), __builtin_bit_cast(us2, ext))) == ext);
+#endif
                     asm volatile(
-                        "v_pk_sub_i16 %[tt], %[xy], %[bx]\n\t"
                         "v_add_f64 %[s0z], %[ax], -%[pxc]\n\t"
-                        "v_pk_max_u16 %[tt], %[tt], %[ext]\n\t"
                         "v_add_f64 %[s1z], %[ay], -%[pyc]\n\t"
                         "v_mov_b64 %[ta], %[c0]\n\t"
-                        "v_cmp_eq_u32_e64 %[cm], %[tt], %[ext]\n\t"
-#ifdef TRGL_DEBUG_COUNTERS
-                        "s_mov_b64 %[am], %[cm]\n\t"
-#endif
                         "v_fmac_f64 %[ta], %[g2], %[s1z]\n\t"
                         "v_fmac_f64 %[ta], %[g1], %[s0z]\n\t"
-                        "v_cmp_nge_f64_e32 vcc, %[ta], %[z]\n\t"
-                        "s_and_b64 %[cm], %[cm], vcc\n\t"
+                        "v_cmp_nge_f64_e64 %[cm], %[ta], %[z]\n\t"
+                        "s_cmp_lg_u64 %[cm], 0\n\t"
                         "s_cbranch_scc0 .Lvisit_end%=\n\t"
                         "v_mul_f64 %[ta], %[s0y], %[s1z]\n\t"
                         "v_mul_f64 %[tb], %[s1y], %[s0z]\n\t"
@@ -770,14 +784,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                         ".Lvisit_end%=:\n\t"
                         "s_mov_b64 %[both], 0\n"
                         ".Lvisit_done%=:"
-                        : [cm] "=&s"(cm), [ux] "=&v"(ux), [uy] "=&v"(uy), [s0z] "=&v"(s0z), [s1z] "=&v"(s1z), [ta] "=&v"(ta), [tb] "=&v"(tb2), [tt] "=&v"(tt),
+                        : [cm] "=&s"(cm), [ux] "=&v"(ux), [uy] "=&v"(uy), [s0z] "=&v"(s0z), [s1z] "=&v"(s1z), [ta] "=&v"(ta), [tb] "=&v"(tb2),
                           [both] "=&s"(both), [sv] "=&s"(sv), [sx] "=&s"(sx), [pend] "+s"(pend), [pux] "+v"(S.pux), [puy] "+v"(S.puy), [ptri] "+v"(S.ptri),
                           [puz] "+v"(S.puz), [pruz] "+v"(S.pruz), [pz0] "+v"(S.pz0), [pz1] "+v"(S.pz1), [pz2] "+v"(S.pz2), [pcd] "+v"(S.pcd)
-#ifdef TRGL_DEBUG_COUNTERS
-                          , [am] "=&s"(am)
-#endif
-                        : [xy] "v"(S.xy), [pxc] "v"(S.pxc), [pyc] "v"(S.pyc), [z] "v"(S.z), [tcur] "s"(tcur),
-                          [bx] "s"(T.bx), [ext] "s"(ext), [ax] "s"(T.ax), [ay] "s"(T.ay), [c0] "s"(T.c0), [g1] "s"(T.g1), [g2] "s"(T.g2),
+                        : [pxc] "v"(S.pxc), [pyc] "v"(S.pyc), [z] "v"(S.z), [tcur] "s"(tcur),
+                          [ax] "s"(T.ax), [ay] "s"(T.ay), [c0] "s"(T.c0), [g1] "s"(T.g1), [g2] "s"(T.g2),
                           [s0x] "s"(T.s0x), [s0y] "s"(T.s0y), [s1x] "s"(T.s1x), [s1y] "s"(T.s1y), [uz] "s"(T.uz),
                           [ruz] "s"(T.ruz), [z0] "s"(T.z0), [z1] "s"(T.z1), [z2] "s"(T.z2), [cd] "s"(KIND == TRGL_SHADER_FLAT ? T.color : T.dl)
                         : "vcc", "scc");
@@ -816,7 +827,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                 // next request, so that inside a visit nothing is outstanding but that request.
                 uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)tri, __builtin_ctzll(surv)), tb;
                 TriScan A = load_scan(recs, ta), B;
-                asm volatile("" :: "s"(A.dl));       // the first triangle's constants are waited for HERE, not behind the first request inside the loop
+                scan_wait(A);                        // the first triangle's constants are waited for HERE, not behind the first request inside the loop
                 for (;;) {
                     surv &= surv - 1;
                     tb = (uint32_t)__builtin_amdgcn_readlane((int)tri, surv ? __builtin_ctzll(surv) : 0);
@@ -824,16 +835,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                     __builtin_amdgcn_sched_barrier(0);
                     visit(A, ta);
                     __builtin_amdgcn_sched_barrier(0);
+                    scan_wait(B);
                     if (!surv) break;
-                    asm volatile("" :: "s"(B.dl));
                     surv &= surv - 1;
                     ta = (uint32_t)__builtin_amdgcn_readlane((int)tri, surv ? __builtin_ctzll(surv) : 0);
                     A = load_scan(recs, ta);
                     __builtin_amdgcn_sched_barrier(0);
                     visit(B, tb);
                     __builtin_amdgcn_sched_barrier(0);
+                    scan_wait(A);
                     if (!surv) break;
-                    asm volatile("" :: "s"(A.dl));
                 }
             }
             TRGL_STAMP(13);        // visits of the round (resolves included; their own clock is counter 14)
@@ -882,6 +893,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
     // ---- stats: our_gl.cpp:194-198, reduced per wave, then per workgroup: one partial per work item (k_fold_stats) ------
     uint32_t frags = S.frags;
     // (std::min over the written depths of a pixel is its last one: the z-test only lets smaller ones through)
+    // (three same-address LDS atomics per wave instead of the butterflies cost 0.5 ms of k_raster: the LDS serialises the 64 lanes)
     unsigned long long kmin = zkey(S.frags ? S.z : __builtin_inf()), kmax = zkey(S.zmax);
     for (int o = 32; o; o >>= 1) {
         frags += __shfl_xor(frags, o);

@@ -326,7 +326,7 @@ int trgl_draw(trgl_ctx* c, int kind, const trgl_uniforms* u, const double* clip,
     // a record addresses its triangle as (draw index, 24-bit index): split larger submissions
     for (uint64_t done = 0; done < n;) {
         uint64_t m = n - done; if (m > TRGL_DRAW_MAX_TRIS) m = TRGL_DRAW_MAX_TRIS;
-        if (c->draws.size() >= TRGL_MAX_DRAWS) { int r = trgl_flush(c); if (r) return r; }
+        if (c->draws.size() >= TRGL_MAX_DRAWS || c->queued_tris + m > TRGL_FLUSH_MAX_TRIS) { int r = trgl_flush(c); if (r) return r; }
         DrawDesc d; std::memset(&d, 0, sizeof(d));
         d.n = (uint32_t)m; d.first = (uint32_t)c->queued_tris; d.kind = kind; d.K = K;
         if (u) d.u = *u; else { d.u.tex_diffuse = d.u.tex_normal = d.u.tex_specular = -1; }

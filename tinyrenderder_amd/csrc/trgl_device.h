@@ -21,8 +21,8 @@
 
 // Per-triangle setup record: everything the pixel loop needs, hoisted exactly as SURVEY §8(a) A4/A6
 // allows (same operations on the same operands as our_gl.cpp:77-86,168-170, so bit-identical).
-// Chunks (16 B) 0-5 are what a block's scan needs as wave-uniform constants (scalar loads: dwordx16 + dwordx8) and what the
-// per-block cull test reads per candidate lane; chunks 3 and 5-7 are gathered per lane when deferred fragments are resolved.
+// The whole record is what a visit of k_raster takes as wave-uniform constants (two scalar loads of 64 B); the per-block cull test
+// reads chunks (16 B) 0-4 and 7 per candidate lane.
 struct alignas(128) TriRec {
     double ax, ay;            // screen[0]                       (our_gl.cpp:117-121)
     double s0x, s0y;          // C.x - A.x, B.x - A.x            (our_gl.cpp:78)
@@ -31,15 +31,16 @@ struct alignas(128) TriRec {
                               //   z > c0 + (ax - x) g1 + (ay - y) g2   (k_setup; c0 = -inf, g = 0: no test)
     double uz;                // s0x*s1y - s0y*s1x = cross().z   (our_gl.cpp:80, geometry.h:147)
     double g1, g2;
-    uint16_t bx0, by0, bx1, by1;   // clamped pixel bbox, inclusive (our_gl.cpp:130-133)
-    uint32_t color;           // FLAT packed BGRA (GOURAUD reads its base colour through `dl`)
-    uint32_t dl;              // bit 31: not "well scaled" (literal divisions, see k_setup) | draw index << 24 | triangle index inside its draw (< 2^24)
     double ruz;               // RN(1/uz) when the triangle is "well scaled" (see setup), else 0:
                               // lets the pixel loop divide by uz with FMAs, bit-identically
     double z0, z1, z2;        // NDC z of the three vertices     (our_gl.cpp:156-158)
+    uint16_t bx0, by0, bx1, by1;   // clamped pixel bbox, inclusive (our_gl.cpp:130-133)
+    uint32_t color;           // FLAT packed BGRA (GOURAUD reads its base colour through `dl`)
+    uint32_t dl;              // bit 31: not "well scaled" (literal divisions, see k_setup) | draw index << 24 | triangle index inside its draw (< 2^24)
 };
 static_assert(sizeof(TriRec) == 128, "TriRec must be one 128-B line");
 #define TRGL_DRAW_MAX_TRIS (1u << 24)   // triangles per DrawDesc; trgl_draw splits larger submissions
+#define TRGL_FLUSH_MAX_TRIS (1u << 25)  // triangles per flush: k_raster addresses a record as base + (index << 7) with a 32-bit scalar offset
 #define TRGL_DL_LITERAL   0x80000000u
 #define TRGL_DL_DRAW(dl)  (((dl) >> 24) & (TRGL_MAX_DRAWS - 1))
 #define TRGL_DL_LOCAL(dl) ((dl) & 0xffffffu)
