@@ -822,29 +822,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                 }
             };
             if (surv) {
+                // The survivors move to lanes 0 .. ns - 1 (through LDS, order kept), so that the visit loop counts instead of peeling bits
+                // off a 64-bit mask: 2 scalar instructions per visit instead of 8 - the scalar unit, one instruction per cycle for the
+                // whole CU, is as busy in this kernel as the vector units.
+                const uint32_t ns = (uint32_t)__popcll(surv);
+                uint32_t* comp = s_out[w];
+                if (keep) comp[__builtin_amdgcn_mbcnt_hi((uint32_t)(surv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)surv, 0u))] = tri;
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t tri_s = comp[lane];            // (lanes >= ns: stale words, never used as an index)
+                __builtin_amdgcn_wave_barrier();
                 // Two sets of constants, A and B, take turns (no register copies): while a visit works on one, the request for
-                // the next survivor's record fills the other.  The wait for a set sits at the top of ITS visit, in front of the
-                // next request, so that inside a visit nothing is outstanding but that request.
-                uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)tri, __builtin_ctzll(surv)), tb;
+                // the next survivor's record fills the other.  The wait for a set sits behind the visit that ran under its request.
+                // (After the last survivor the request repeats it: a valid address, nobody reads the result.)
+                uint32_t i = 0;
+                uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)tri_s, 0), tb;
                 TriScan A = load_scan(recs, ta), B;
                 scan_wait(A);                        // the first triangle's constants are waited for HERE, not behind the first request inside the loop
                 for (;;) {
-                    surv &= surv - 1;
-                    tb = (uint32_t)__builtin_amdgcn_readlane((int)tri, surv ? __builtin_ctzll(surv) : 0);
+                    tb = (uint32_t)__builtin_amdgcn_readlane((int)tri_s, (int)min(i + 1u, ns - 1u));
                     B = load_scan(recs, tb);
                     __builtin_amdgcn_sched_barrier(0);
                     visit(A, ta);
                     __builtin_amdgcn_sched_barrier(0);
                     scan_wait(B);
-                    if (!surv) break;
-                    surv &= surv - 1;
-                    ta = (uint32_t)__builtin_amdgcn_readlane((int)tri, surv ? __builtin_ctzll(surv) : 0);
+                    if (++i >= ns) break;
+                    ta = (uint32_t)__builtin_amdgcn_readlane((int)tri_s, (int)min(i + 1u, ns - 1u));
                     A = load_scan(recs, ta);
                     __builtin_amdgcn_sched_barrier(0);
                     visit(B, tb);
                     __builtin_amdgcn_sched_barrier(0);
                     scan_wait(A);
-                    if (!surv) break;
+                    if (++i >= ns) break;
                 }
             }
             TRGL_STAMP(13);        // visits of the round (resolves included; their own clock is counter 14)
