@@ -740,15 +740,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
 #ifdef TRGL_DEBUG_COUNTERS
                     am = __ballot(__builtin_bit_cast(uint32_t, __builtin_elementwise_max(S.xy - __builtin_bit_cast(us2, T.bx), __builtin_bit_cast(us2, ext))) == ext);
 #endif
+                    // (`asm goto` would let the exits of this block skip the test of `both` behind it; this compiler's AMDGPU back end
+                    // loses the block's contents when it has branch targets outside, so the exits set both = 0 and fall out.)
                     asm volatile(
                         "v_add_f64 %[s0z], %[ax], -%[pxc]\n\t"
                         "v_add_f64 %[s1z], %[ay], -%[pyc]\n\t"
                         "v_mov_b64 %[ta], %[c0]\n\t"
                         "v_fmac_f64 %[ta], %[g2], %[s1z]\n\t"
                         "v_fmac_f64 %[ta], %[g1], %[s0z]\n\t"
-                        "v_cmp_nge_f64_e64 %[cm], %[ta], %[z]\n\t"
-                        "s_cmp_lg_u64 %[cm], 0\n\t"
-                        "s_cbranch_scc0 .Lvisit_end%=\n\t"
+                        "v_cmp_nge_f64_e32 vcc, %[ta], %[z]\n\t"
+#ifdef TRGL_DEBUG_COUNTERS
+                        "s_mov_b64 %[cm], 0\n\t"
+#endif
+                        "s_cbranch_vccz .Lvisit_end%=\n\t"
                         "v_mul_f64 %[ta], %[s0y], %[s1z]\n\t"
                         "v_mul_f64 %[tb], %[s1y], %[s0z]\n\t"
                         "v_add_f64 %[ux], %[ta], -%[tb]\n\t"
@@ -757,17 +761,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                         "v_add_f64 %[uy], %[ta], -%[tb]\n\t"
                         "v_add_f64 %[ta], %[ux], %[uy]\n\t"
                         "v_max_f64 %[tb], %[ux], %[uy]\n\t"
-                        "v_cmp_nlt_f64_e64 vcc, %[ta], %[uz]\n\t"
+                        "v_cmp_nlt_f64_e64 %[cm], %[ta], %[uz]\n\t"
                         "s_and_b64 %[cm], %[cm], vcc\n\t"
                         "v_cmp_nlt_f64_e32 vcc, 0, %[tb]\n\t"
                         "s_and_b64 %[cm], %[cm], vcc\n\t"
                         "s_cbranch_scc0 .Lvisit_end%=\n\t"
                         // covered lanes: those that hold no fragment note (u.x, u.y, triangle) at once, in place (moves under the mask);
-                        // `both` = the covered lanes that still hold one (the caller resolves first, then notes theirs)
-                        "s_and_b64 %[both], %[cm], %[pend]\n\t"
-                        "s_or_b64 %[pend], %[pend], %[cm]\n\t"
-                        "s_xor_b64 %[sv], %[cm], %[both]\n\t"
-                        "s_cbranch_scc0 .Lvisit_done%=\n\t"
+                        // `both` = the covered lanes that still hold one (the code behind the block resolves first, then notes theirs)
+                        "s_andn2_b64 %[sv], %[cm], %[pend]\n\t"
+                        "s_cbranch_scc0 .Lvisit_noted%=\n\t"
                         "s_mov_b64 %[sx], exec\n\t"
                         "s_mov_b64 exec, %[sv]\n\t"
                         "v_mov_b64 %[pux], %[ux]\n\t"
@@ -779,7 +781,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                         "v_mov_b64 %[pz1], %[z1]\n\t"
                         "v_mov_b64 %[pz2], %[z2]\n\t"
                         "v_mov_b32 %[pcd], %[cd]\n\t"
-                        "s_mov_b64 exec, %[sx]\n\t"
+                        "s_mov_b64 exec, %[sx]\n"
+                        ".Lvisit_noted%=:\n\t"
+                        "s_or_b64 %[pend], %[pend], %[cm]\n\t"
+                        "s_xor_b64 %[both], %[cm], %[sv]\n\t"
                         "s_branch .Lvisit_done%=\n"
                         ".Lvisit_end%=:\n\t"
                         "s_mov_b64 %[both], 0\n"
@@ -810,7 +815,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                     note(cm & ~pend, ux, uy);
                     pend |= cm;
                 }
-                TRGL_DBG(2, 1); TRGL_DBG(3, __popcll(am)); TRGL_DBG(4, cm ? 1 : 0); TRGL_DBG(5, __popcll(cm));
+                TRGL_DBG(2, tcur < fp.n_tris ? 1 : 0); TRGL_DBG(3, __popcll(am)); TRGL_DBG(4, cm ? 1 : 0); TRGL_DBG(5, __popcll(cm));
                 if (both) {
                     // Some covered lanes still hold a fragment of an earlier triangle, which has to be resolved first (submission
                     // order per pixel).  Everything that can go goes in that one pass: the old fragments of all noted lanes AND the
@@ -818,7 +823,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                     // stay noted afterwards.
                     resolve<KIND, ALLWS, DEFERRED>(S, pend, recs, recs_w, draws, stats, zero_locked);
                     note(both, ux, uy);
-                    pend = both;
+                    asm volatile("s_mov_b64 %0, %1" : "+s"(pend) : "s"(both));      // pend = both, in the register that holds it
                 }
             };
             if (surv) {
@@ -829,31 +834,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                 uint32_t* comp = s_out[w];
                 if (keep) comp[__builtin_amdgcn_mbcnt_hi((uint32_t)(surv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)surv, 0u))] = tri;
                 __builtin_amdgcn_wave_barrier();
-                const uint32_t tri_s = comp[lane];            // (lanes >= ns: stale words, never used as an index)
-                __builtin_amdgcn_wave_barrier();
+                uint32_t tri_s = comp[lane];
+                // The lanes behind them name the record behind the flush's last one (k_make_items): the loop below runs in PAIRS of visits -
+                // one counter update and one exit test per pair - and the partner of an odd last survivor is that record, whose
+                // visit ends at its first test.
+                if ((uint32_t)lane >= ns) tri_s = fp.n_tris;
                 // Two sets of constants, A and B, take turns (no register copies): while a visit works on one, the request for
                 // the next survivor's record fills the other.  The wait for a set sits behind the visit that ran under its request.
-                // (After the last survivor the request repeats it: a valid address, nobody reads the result.)
+                // (The last request of a round names lane ns + 1 or, behind lane 63, lane 0 or 1: valid addresses, nobody reads the result.)
                 uint32_t i = 0;
                 uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)tri_s, 0), tb;
                 TriScan A = load_scan(recs, ta), B;
                 scan_wait(A);                        // the first triangle's constants are waited for HERE, not behind the first request inside the loop
-                for (;;) {
-                    tb = (uint32_t)__builtin_amdgcn_readlane((int)tri_s, (int)min(i + 1u, ns - 1u));
+                do {
+                    tb = (uint32_t)__builtin_amdgcn_readlane((int)tri_s, (int)(i + 1u));
                     B = load_scan(recs, tb);
                     __builtin_amdgcn_sched_barrier(0);
                     visit(A, ta);
                     __builtin_amdgcn_sched_barrier(0);
                     scan_wait(B);
-                    if (++i >= ns) break;
-                    ta = (uint32_t)__builtin_amdgcn_readlane((int)tri_s, (int)min(i + 1u, ns - 1u));
+                    ta = (uint32_t)__builtin_amdgcn_readlane((int)tri_s, (int)(i + 2u));
                     A = load_scan(recs, ta);
                     __builtin_amdgcn_sched_barrier(0);
                     visit(B, tb);
                     __builtin_amdgcn_sched_barrier(0);
                     scan_wait(A);
-                    if (++i >= ns) break;
-                }
+                    i += 2;
+                } while (i < ns);
             }
             TRGL_STAMP(13);        // visits of the round (resolves included; their own clock is counter 14)
         }
@@ -1066,9 +1073,18 @@ __global__ void k_selftest_sampler(const DevTexture* __restrict__ tex, int slot,
 // does not start from clear, and block rows entirely outside the strip get no item.
 __global__ __launch_bounds__(256) void k_make_items(FrameParams fp, const uint32_t* __restrict__ tile_start,
                                                     const uint32_t* __restrict__ tile_end,
-                                                    uint4* __restrict__ items, uint32_t* __restrict__ n_items) {
+                                                    uint4* __restrict__ items, uint32_t* __restrict__ n_items, TriRec* __restrict__ recs) {
     const int ntiles_strip = (fp.strip_ty1 - fp.strip_ty0) * fp.tiles_x;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    // The record behind the flush's last one belongs to no triangle: k_raster visits it when a cull round leaves an odd number of
+    // survivors (its visit loop runs in pairs).  Its depth plane is +inf everywhere, so no pixel is in front of its stored depth and
+    // the visit ends at its first test; should a pixel hold NaN (which lets every plane through), u.z = 1 > 0 = u.x + u.y fails coverage.
+    if (k == 0 && fp.n_tris) {
+        TriRec d;
+        d.ax = d.ay = d.s0x = d.s0y = d.s1x = d.s1y = 0.0; d.c0 = __builtin_inf(); d.uz = 1.0; d.g1 = d.g2 = 0.0;
+        d.ruz = 0.0; d.z0 = d.z1 = d.z2 = 0.0; d.bx0 = d.by0 = 1; d.bx1 = d.by1 = 0; d.color = 0; d.dl = 0;
+        recs[fp.n_tris] = d;
+    }
     uint32_t nb = 0, t = 0, rows = 0;          // rows: bit r set = block row r of the tile gets an item
     uint32_t beg = 0, end = 0;
     bool clear_only = false;
@@ -1183,7 +1199,7 @@ void launch_raster(hipStream_t s, const FrameParams& fp, int kind /* TRGL_SHADER
         hipLaunchKernelGGL(k_fold_stats, dim3(FOLD_BLOCKS), dim3(1024), 0, s, stats, n_items, item_stats);     // n_items is 0: only resets the per-flush counts
         return;
     }
-    hipLaunchKernelGGL(k_make_items, dim3((tiles + 255) / 256), dim3(256), 0, s, fp, tile_start, tile_end, items, n_items);
+    hipLaunchKernelGGL(k_make_items, dim3((tiles + 255) / 256), dim3(256), 0, s, fp, tile_start, tile_end, items, n_items, const_cast<TriRec*>(recs));
     dim3 grid(((max_items + 7u) / 8u) * 8u);    // workgroup b -> item (b mod 8) * ceil(G / 8) + b / 8 (k_raster)
     if (ev_before) (void)hipEventRecord(ev_before, s);
 #define TRGL_LAUNCH_RASTER(...) hipLaunchKernelGGL((k_raster<__VA_ARGS__>), grid, dim3(256), 0, s, fp, recs, recs_w, vals, bmask, tile_start, tile_end, draws, stats, items, n_items, item_stats)

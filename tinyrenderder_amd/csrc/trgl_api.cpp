@@ -522,7 +522,7 @@ int trgl_flush_begin(trgl_ctx* c) {
     int cur = 0;
     if (N) {
         // grow per-triangle buffers together
-        if (N > c->cap_tris) {
+        if (N + 1 > c->cap_tris) {                     // (+ 1: the record behind the last one, k_make_items)
             size_t ncap = N + N / 4 + 1024;
             if ((r = realloc_dev(c, (void**)&c->recs, ncap * sizeof(TriRec)))) return r;
             if ((r = realloc_dev(c, (void**)&c->recs_w, ncap * sizeof(TriW)))) return r;

@@ -40,7 +40,7 @@ struct alignas(128) TriRec {
 };
 static_assert(sizeof(TriRec) == 128, "TriRec must be one 128-B line");
 #define TRGL_DRAW_MAX_TRIS (1u << 24)   // triangles per DrawDesc; trgl_draw splits larger submissions
-#define TRGL_FLUSH_MAX_TRIS (1u << 25)  // triangles per flush: k_raster addresses a record as base + (index << 7) with a 32-bit scalar offset
+#define TRGL_FLUSH_MAX_TRIS ((1u << 25) - 1u)  // triangles per flush: k_raster addresses a record (and the one behind the last) as base + (index << 7) with a 32-bit scalar offset
 #define TRGL_DL_LITERAL   0x80000000u
 #define TRGL_DL_DRAW(dl)  (((dl) >> 24) & (TRGL_MAX_DRAWS - 1))
 #define TRGL_DL_LOCAL(dl) ((dl) & 0xffffffu)
