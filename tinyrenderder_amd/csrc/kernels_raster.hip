@@ -328,6 +328,12 @@ __device__ __forceinline__ TriScan load_scan(const TriRec* __restrict__ recs, ui
     TriScan::u32x16 g, h;
     asm volatile("s_load_dwordx16 %0, %2, %3 offset:0x0\n\ts_load_dwordx16 %1, %2, %3 offset:0x40" : "=&s"(g), "=&s"(h) : "s"(recs), "s"(tri << 7));
     T.lo = g; T.hi = h;
+#ifdef TRGL_DEBUG_COUNTERS
+    // (the diagnostic build keeps so many counters in scalar registers that the compiler spills a set while its request is still out -
+    // tools/check_scan_regs.py refuses that; here the request is waited for at once, which costs the visits of THIS build their overlap)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(T.lo), "+s"(T.hi) :: "memory");
+    g = T.lo; h = T.hi;
+#endif
     auto dg = [&](int i) { return __builtin_bit_cast(double, ((unsigned long long)g[i + 1] << 32) | g[i]); };
     auto dh = [&](int i) { return __builtin_bit_cast(double, ((unsigned long long)h[i + 1] << 32) | h[i]); };
     T.ax = dg(0); T.ay = dg(2); T.s0x = dg(4); T.s0y = dg(6); T.s1x = dg(8); T.s1y = dg(10); T.c0 = dg(12); T.uz = dg(14);
@@ -522,7 +528,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
     constexpr bool DEFERRED = KIND == TRGL_SHADER_PHONG || KIND == TRGL_SHADER_EYE || KIND == KIND_ANY;
     __shared__ uint32_t s_ring[4][RING];
     __shared__ uint32_t s_out[4][64];
-    __shared__ unsigned long long s_part[4][3];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): workgroup b runs on the XCD of b mod 8.  Give every
@@ -906,27 +911,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
 
     TRGL_STAMP(15);                // block out
     // ---- stats: our_gl.cpp:194-198, reduced per wave, then per workgroup: one partial per work item (k_fold_stats) ------
-    uint32_t frags = S.frags;
     // (std::min over the written depths of a pixel is its last one: the z-test only lets smaller ones through)
-    // (three same-address LDS atomics per wave instead of the butterflies cost 0.5 ms of k_raster: the LDS serialises the 64 lanes)
-    unsigned long long kmin = zkey(S.frags ? S.z : __builtin_inf()), kmax = zkey(S.zmax);
-    for (int o = 32; o; o >>= 1) {
-        frags += __shfl_xor(frags, o);
-        unsigned long long a = __shfl_xor(kmin, o); kmin = a < kmin ? a : kmin;
-        unsigned long long b = __shfl_xor(kmax, o); kmax = b > kmax ? b : kmax;
+    // One reduction per WORKGROUP: every lane leaves its three values in its wave's candidate ring (done with by now), and behind the
+    // kernel's only block-level barrier the first wave folds the four waves' values lane by lane and runs the butterflies once
+    // (~100 vector + 30 LDS instructions that three of four waves no longer spend; three same-address LDS atomics per wave instead
+    // cost 0.5 ms of k_raster - the LDS serialises the 64 lanes).
+    {
+        unsigned long long* red = reinterpret_cast<unsigned long long*>(ring);       // [0..63] smallest, [64..127] largest depth key, then the counts
+        red[lane] = zkey(S.frags ? S.z : __builtin_inf());
+        red[64 + lane] = zkey(S.zmax);
+        ring[256 + lane] = S.frags;
     }
 #ifdef TRGL_DEBUG_COUNTERS
     for (int o = 32; o; o >>= 1) S.dbg[8] += __shfl_xor(S.dbg[8], o);
     if (lane == 0) for (int k = 0; k < 16; ++k) if (S.dbg[k]) atomicAdd(&stats->dbg[k], S.dbg[k]);
 #endif
-    if (lane == 0) { s_part[w][0] = frags; s_part[w][1] = kmin; s_part[w][2] = kmax; }
     __syncthreads();                 // the only block-level barrier of the kernel, when every wave of the workgroup is done
-    if (threadIdx.x == 0) {
-        unsigned long long f = 0, mn = ~0ull, mx = 0ull;
-        for (int k = 0; k < 4; ++k) { f += s_part[k][0]; mn = s_part[k][1] < mn ? s_part[k][1] : mn; mx = s_part[k][2] > mx ? s_part[k][2] : mx; }
-        ulonglong2* dst = reinterpret_cast<ulonglong2*>(my_stats);
-        dst[0] = make_ulonglong2(f, mn);
-        dst[1] = make_ulonglong2(mx, 0ull);
+    if (w == 0) {
+        unsigned long long frags = 0, kmin = ~0ull, kmax = 0ull;
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long* red = reinterpret_cast<const unsigned long long*>(s_ring[k]);
+            const unsigned long long a = red[lane], b = red[64 + lane];
+            frags += s_ring[k][256 + lane]; kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+        }
+        for (int o = 32; o; o >>= 1) {
+            frags += __shfl_xor(frags, o);
+            unsigned long long a = __shfl_xor(kmin, o); kmin = a < kmin ? a : kmin;
+            unsigned long long b = __shfl_xor(kmax, o); kmax = b > kmax ? b : kmax;
+        }
+        if (lane == 0) {
+            ulonglong2* dst = reinterpret_cast<ulonglong2*>(my_stats);
+            dst[0] = make_ulonglong2(frags, kmin);
+            dst[1] = make_ulonglong2(kmax, 0ull);
+        }
     }
 }
 
