@@ -62,7 +62,9 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
         const double2* s2 = reinterpret_cast<const double2*>(src);
         double2* l2 = reinterpret_cast<double2*>(s_buf);
-        for (uint32_t k = tid; k < nb * 6; k += SETUP_THREADS) l2[k] = s2[k];
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        for (uint32_t k = tid; k < nb * 6; k += SETUP_THREADS)
+            *reinterpret_cast<f64x2*>(&l2[k]) = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(&s2[k]));
     } else {
         for (uint32_t k = tid; k < nb * 12; k += SETUP_THREADS) s_buf[k] = src[k];
     }
@@ -210,7 +212,10 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const uint32_t k = lane + 64u * it, t = k >> 3, c = k & 7;            // chunk c of the wave's record t
-            if ((keep >> t) & 1ull) dst[k] = l4[(wbase + t) * 8 + (c ^ (t & 7))];
+            if ((keep >> t) & 1ull) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(&l4[(wbase + t) * 8 + (c ^ (t & 7))]), reinterpret_cast<u32x4*>(&dst[k]));
+            }
         }
     }
     // pairs of this block of 256 triangles: k_expand derives every triangle's slice of the pair list from these sums
