@@ -608,12 +608,15 @@ def test_more_draws_than_descriptors_between_flushes():
     assert np.array_equal(fb, o.fb) and np.array_equal(z.view(np.uint64), o.z.view(np.uint64)) and st == o.stats
 
 
-def test_one_draw_of_more_than_2_to_24_triangles():
+@pytest.mark.parametrize("log2n", [24, 25])
+def test_one_draw_of_more_than_2_to_24_triangles(log2n):
     """A record addresses its triangle as (draw, 24-bit index), so trgl_draw splits a submission of 2^24 + 40 000 triangles into
     two descriptors whose clip / colour pointers are offset.  The last 40 000 triangles (the second descriptor) are the
-    visible ones: wrong offsets would show as wrong colours or positions.  Host arrays (1.6 GB of clip data)."""
+    visible ones: wrong offsets would show as wrong colours or positions.  Host arrays (1.6 GB of clip data).
+    2^25 + 40 000: k_raster addresses a record as base + (index << 7) with a 32-bit offset, so trgl_draw also starts a new FLUSH
+    before the 2^25-th triangle of one (TRGL_FLUSH_MAX_TRIS); the frame must not show where."""
     W, H = 256, 256
-    n_small, n_vis = (1 << 24) + 3000, 37_000
+    n_small, n_vis = (1 << log2n) + 3000, 37_000
     vis, vcol = scenes.random_triangles(n_vis + 3000, W, H, seed=91, rmin=2, rmax=30)
     clip = np.empty((n_small + n_vis, 12))
     col = (np.arange(n_small + n_vis, dtype=np.uint64) * np.uint64(2654435761) & np.uint64(0xFFFFFF)).astype(np.uint32) | np.uint32(0xFF000000)
