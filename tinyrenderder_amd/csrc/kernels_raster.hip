@@ -586,6 +586,138 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
     // load of block masks; steps start at a multiple of 4 entries, the pair buffers hold a multiple of 4).  The entries of the next
     // step are requested before the candidates of this one are processed.  Loads without a branch around them (clamped index, masks
     // cleared outside [beg, end)), so that the wait for THIS step's entries can leave the next step's loads in flight.
+    // the round whose gather is in flight: its candidates (lane = candidate), how many, and chunks 0-4 and 7 of their records
+    uint32_t pn = 0, ptri = 0;
+    double2 pq0 = make_double2(0, 0), pq1 = pq0, pq2 = pq0, pq3 = pq0, pq4 = pq0;
+    uint4 pq5 = make_uint4(0, 0, 0, 0);
+    // ---- visits: the survivors in list order, constants through the scalar cache one visit ahead -------------------
+    // One visit = our_gl.cpp:147-152 for one triangle on this block, one pixel per lane, up to the coverage decision.
+    auto visit = [&](const TriScan& T, uint32_t tcur) {
+        // the lanes of `m` note (u.x, u.y, triangle): moves under the mask, in place
+        auto note = [&](unsigned long long m, double ux, double uy) {
+            unsigned long long sv;
+            asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\tv_mov_b64 %[px], %[ux]\n\tv_mov_b64 %[py], %[uy]\n\t"
+                         "v_mov_b32 %[pt], %[t]\n\tv_mov_b64 %[puz], %[uz]\n\tv_mov_b64 %[pruz], %[ruz]\n\t"
+                         "v_mov_b64 %[pz0], %[z0]\n\tv_mov_b64 %[pz1], %[z1]\n\tv_mov_b64 %[pz2], %[z2]\n\tv_mov_b32 %[pcd], %[cd]\n\ts_mov_b64 exec, %[sv]"
+                         : [px] "+v"(S.pux), [py] "+v"(S.puy), [pt] "+v"(S.ptri), [sv] "=&s"(sv),
+                           [puz] "+v"(S.puz), [pruz] "+v"(S.pruz), [pz0] "+v"(S.pz0), [pz1] "+v"(S.pz1), [pz2] "+v"(S.pz2), [pcd] "+v"(S.pcd)
+                         : [ux] "v"(ux), [uy] "v"(uy), [t] "s"(tcur), [m] "s"(m), [cd] "s"(KIND == TRGL_SHADER_FLAT ? T.color : T.dl),
+                           [uz] "s"(T.uz), [ruz] "s"(T.ruz), [z0] "s"(T.z0), [z1] "s"(T.z1), [z2] "s"(T.z2));
+        };
+        double ux, uy;
+        unsigned long long cm;                    // lanes with a covered pixel that can still win the z-test (wave-uniform)
+        unsigned long long both, sv, sx;          // ... that still hold a fragment of an earlier triangle; scratch
+#ifdef TRGL_DEBUG_COUNTERS
+        unsigned long long am = 0;
+#endif
+        const uint32_t ext = T.by - T.bx;         // (hi >= lo in both 16-bit halves: no borrow)
+        if (ALLWS || !(T.dl & TRGL_DL_LITERAL)) {
+            // The core of a visit is written out instruction by instruction: 19 vector + 4 scalar instructions, straight-line
+            // but for one branch.  (From C++ the compiler builds it with exec-mask regions: zero-initialised phi registers,
+            // save / restore pairs and a mask -> vector -> mask round trip for the ballot: ~30 vector + ~25 scalar.)  Every
+            // vector instruction issues for all 64 lanes whether they matter or not, so nothing is masked: lanes outside
+            // (bbox n block), hidden lanes and uncovered lanes only drop out of the final mask.
+            //   NO test of the lane's pixel against the triangle's bbox (our_gl.cpp:130-133 only visits bbox pixels): a pixel centre
+            //     outside floor(min) .. ceil(max) is at least half a pixel away from the triangle, and k_setup sends every triangle
+            //     for which the roundings of u could bridge that (2^-40 S^2 R >= |u.z|) down the literal path below, which keeps the
+            //     test.  Pixels beyond the image or outside the strip hold -inf and fail the depth comparison.
+            //   barycentric(), our_gl.cpp:77-86: s0z = ax - x, s1z = ay - y (s0.xy, s1.xy and u.z hoisted into the record)
+            //   depth first: zpl = fma(s0z, g1, fma(s1z, g2, c0)); a pixel with zpl >= its stored depth fails the z-test whatever
+            //     its coverage (k_setup); NaN reads as keep.  No lane left: the visit ends here.
+            //   u.x = s0y s1z - s0z s1y (geometry.h:145), u.y = s0z s1x - s0x s1z (:146), us = u.x + u.y, every product and sum
+            //     rounded on its own as in the reference
+            //   covered <=> !(us < u.z) && !(u.y > 0) && !(u.x > 0): u.z < 0 and nothing can over/underflow, so the signs of the
+            //     quotients of :85 are known without dividing ("exactness"); max(u.x, u.y) > 0 <=> one of them is.
+            double s0z, s1z, ta, tb2;
+#ifdef TRGL_DEBUG_COUNTERS
+            am = __ballot(__builtin_bit_cast(uint32_t, __builtin_elementwise_max(S.xy - __builtin_bit_cast(us2, T.bx), __builtin_bit_cast(us2, ext))) == ext);
+#endif
+            // (`asm goto` would let the exits of this block skip the test of `both` behind it; this compiler's AMDGPU back end
+            // loses the block's contents when it has branch targets outside, so the exits set both = 0 and fall out.)
+            asm volatile(
+                "v_add_f64 %[s0z], %[ax], -%[pxc]\n\t"
+                "v_add_f64 %[s1z], %[ay], -%[pyc]\n\t"
+                "v_mov_b64 %[ta], %[c0]\n\t"
+                "v_fmac_f64 %[ta], %[g2], %[s1z]\n\t"
+                "v_fmac_f64 %[ta], %[g1], %[s0z]\n\t"
+                "v_cmp_nge_f64_e32 vcc, %[ta], %[z]\n\t"
+#ifdef TRGL_DEBUG_COUNTERS
+                "s_mov_b64 %[cm], 0\n\t"
+#endif
+                "s_cbranch_vccz .Lvisit_end%=\n\t"
+                "v_mul_f64 %[ta], %[s0y], %[s1z]\n\t"
+                "v_mul_f64 %[tb], %[s1y], %[s0z]\n\t"
+                "v_add_f64 %[ux], %[ta], -%[tb]\n\t"
+                "v_mul_f64 %[ta], %[s1x], %[s0z]\n\t"
+                "v_mul_f64 %[tb], %[s0x], %[s1z]\n\t"
+                "v_add_f64 %[uy], %[ta], -%[tb]\n\t"
+                "v_add_f64 %[ta], %[ux], %[uy]\n\t"
+                "v_max_f64 %[tb], %[ux], %[uy]\n\t"
+                "v_cmp_nlt_f64_e64 %[cm], %[ta], %[uz]\n\t"
+                "s_and_b64 %[cm], %[cm], vcc\n\t"
+                "v_cmp_nlt_f64_e32 vcc, 0, %[tb]\n\t"
+                "s_and_b64 %[cm], %[cm], vcc\n\t"
+                "s_cbranch_scc0 .Lvisit_end%=\n\t"
+                // covered lanes: those that hold no fragment note (u.x, u.y, triangle) at once, in place (moves under the mask);
+                // `both` = the covered lanes that still hold one (the code behind the block resolves first, then notes theirs)
+                "s_andn2_b64 %[sv], %[cm], %[pend]\n\t"
+                "s_cbranch_scc0 .Lvisit_noted%=\n\t"
+                "s_mov_b64 %[sx], exec\n\t"
+                "s_mov_b64 exec, %[sv]\n\t"
+                "v_mov_b64 %[pux], %[ux]\n\t"
+                "v_mov_b64 %[puy], %[uy]\n\t"
+                "v_mov_b32 %[ptri], %[tcur]\n\t"
+                "v_mov_b64 %[puz], %[uz]\n\t"
+                "v_mov_b64 %[pruz], %[ruz]\n\t"
+                "v_mov_b64 %[pz0], %[z0]\n\t"
+                "v_mov_b64 %[pz1], %[z1]\n\t"
+                "v_mov_b64 %[pz2], %[z2]\n\t"
+                "v_mov_b32 %[pcd], %[cd]\n\t"
+                "s_mov_b64 exec, %[sx]\n"
+                ".Lvisit_noted%=:\n\t"
+                "s_or_b64 %[pend], %[pend], %[cm]\n\t"
+                "s_xor_b64 %[both], %[cm], %[sv]\n\t"
+                "s_branch .Lvisit_done%=\n"
+                ".Lvisit_end%=:\n\t"
+                "s_mov_b64 %[both], 0\n"
+                ".Lvisit_done%=:"
+                : [cm] "=&s"(cm), [ux] "=&v"(ux), [uy] "=&v"(uy), [s0z] "=&v"(s0z), [s1z] "=&v"(s1z), [ta] "=&v"(ta), [tb] "=&v"(tb2),
+                  [both] "=&s"(both), [sv] "=&s"(sv), [sx] "=&s"(sx), [pend] "+s"(pend), [pux] "+v"(S.pux), [puy] "+v"(S.puy), [ptri] "+v"(S.ptri),
+                  [puz] "+v"(S.puz), [pruz] "+v"(S.pruz), [pz0] "+v"(S.pz0), [pz1] "+v"(S.pz1), [pz2] "+v"(S.pz2), [pcd] "+v"(S.pcd)
+                : [pxc] "v"(S.pxc), [pyc] "v"(S.pyc), [z] "v"(S.z), [tcur] "s"(tcur),
+                  [ax] "s"(T.ax), [ay] "s"(T.ay), [c0] "s"(T.c0), [g1] "s"(T.g1), [g2] "s"(T.g2),
+                  [s0x] "s"(T.s0x), [s0y] "s"(T.s0y), [s1x] "s"(T.s1x), [s1y] "s"(T.s1y), [uz] "s"(T.uz),
+                  [ruz] "s"(T.ruz), [z0] "s"(T.z0), [z1] "s"(T.z1), [z2] "s"(T.z2), [cd] "s"(KIND == TRGL_SHADER_FLAT ? T.color : T.dl)
+                : "vcc", "scc");
+        } else {
+            // a triangle that is not well scaled: the same visit from C++, coverage from the literal quotients of :85
+            const us2 off = S.xy - __builtin_bit_cast(us2, T.bx);
+            const bool act = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(off, __builtin_bit_cast(us2, ext))) == ext;
+            const double s0z = T.ax - S.pxc, s1z = T.ay - S.pyc;
+            const double zpl = __builtin_fma(s0z, T.g1, __builtin_fma(s1z, T.g2, T.c0));
+            ux = T.s0y * s1z - s0z * T.s1y;                               // geometry.h:145
+            uy = s0z * T.s1x - T.s0x * s1z;                               // geometry.h:146
+            const double us = ux + uy;
+            const double b0 = 1.0 - us / T.uz, b1 = uy / T.uz, b2 = ux / T.uz;      // :85, as written
+            cm = __ballot(act && !(zpl >= S.z) && !(b0 < 0 || b1 < 0 || b2 < 0));  // :152
+#ifdef TRGL_DEBUG_COUNTERS
+            am = __ballot(act);
+#endif
+            both = cm & pend;
+            note(cm & ~pend, ux, uy);
+            pend |= cm;
+        }
+        TRGL_DBG(2, tcur < fp.n_tris ? 1 : 0); TRGL_DBG(3, __popcll(am)); TRGL_DBG(4, cm ? 1 : 0); TRGL_DBG(5, __popcll(cm));
+        if (both) {
+            // Some covered lanes still hold a fragment of an earlier triangle, which has to be resolved first (submission
+            // order per pixel).  Everything that can go goes in that one pass: the old fragments of all noted lanes AND the
+            // new ones of the lanes that held none (`pend` holds them already); only the conflicting lanes' new fragments
+            // stay noted afterwards.
+            resolve<KIND, ALLWS, DEFERRED>(S, pend, recs, recs_w, draws, stats, zero_locked);
+            note(both, ux, uy);
+            asm volatile("s_mov_b64 %0, %1" : "+s"(pend) : "s"(both));      // pend = both, in the register that holds it
+        }
+    };
     const uint32_t p_first = beg & ~3u;
     auto load_step = [&](uint32_t p0, uint4& tri4, uint2& m) {
         const uint32_t pl = p0 + 4u * (uint32_t)lane, p = min(pl, (end - 1u) & ~3u);
@@ -646,191 +778,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
         }
         const bool last = p0 + 256 >= end;
         TRGL_STAMP(11);            // list step: wait for its entries, append the candidates
-        while (cnt >= 64 || (last && cnt)) {
-            const uint32_t n = cnt < 64 ? cnt : 64;
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t tri = ring[(head + lane) & (RING - 1)];
-            __builtin_amdgcn_wave_barrier();
-            head += n; cnt -= n;
+        // Rounds of up to 64 candidates, two in the pipe: the gather of round k + 1 is REQUESTED between the test of round k and the
+        // visits of its survivors, so that it flies under them; its test follows the visits and sees the depths they left.  A
+        // requested round also stays in flight over a list step when the ring cannot start the one after it yet.
+        for (;;) {
+            const bool can = cnt >= 64 || (last && cnt);
+            bool keep = false;
+            if (pn) {
+                if (!can && !last) break;
             // ---- cull: lane = candidate ------------------------------------------------------------------------------
-            // largest stored depth of the block (deferred fragments only lower depths later: a stale maximum stays a bound;
-            // a pixel holding NaN can never be written again, v_max skips it)
-            // (as a float rounded up: six v_max_f32 with DPP / permlane operands instead of 64-bit shuffles through LDS)
-            const double zmaxb = (double)wave_max_f32(f32_up(S.z));
-            bool keep = (uint32_t)lane < n;
+                // largest stored depth of the block (deferred fragments only lower depths later: a stale maximum stays a bound;
+                // a pixel holding NaN can never be written again, v_max skips it)
+                // (as a float rounded up: six v_max_f32 with DPP / permlane operands instead of 64-bit shuffles through LDS)
+                const double zmaxb = (double)wave_max_f32(f32_up(S.z));
+                keep = (uint32_t)lane < pn;
 #ifdef TRGL_DEBUG_COUNTERS
-            if (keep && tri >= fp.n_tris) { atomicAdd(&stats->dbg[9], 1ull); keep = false; }      // must stay 0: a list entry that is no triangle
+                if (keep && ptri >= fp.n_tris) { atomicAdd(&stats->dbg[9], 1ull); keep = false; }      // must stay 0: a list entry that is no triangle
 #endif
-            if (keep) {
-                const double2* q = reinterpret_cast<const double2*>(recs + tri);
-                const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
-                const uint4 q5 = reinterpret_cast<const uint4*>(q)[7];
-                if (ALLWS || !(q5.w & TRGL_DL_LITERAL)) {
-                    const double ax = q0.x, ay = q0.y, s0x = q1.x, s0y = q1.y, s1x = q2.x, s1y = q2.y, c0 = q3.x, uz = q3.y, g1 = q4.x, g2 = q4.y;
-                    // pixel centres of (bbox n block): [xlo, xhi] x [ylo, yhi]
-                    const int bx0 = (int)(q5.x & 0xffffu), by0 = (int)(q5.x >> 16), bx1 = (int)(q5.y & 0xffffu), by1 = (int)(q5.y >> 16);
-                    const double xlo = (double)max(bx0, X0) + 0.5, xhi = (double)min(bx1, X0 + 7) + 0.5;
-                    const double ylo = (double)max(by0, Y0) + 0.5, yhi = (double)min(by1, Y0 + 7) + 0.5;
-                    // (edge)  a pixel is covered iff the rounded u.x <= 0, u.y <= 0 and u.x + u.y >= u.z (the sign form of :152);
-                    // each is affine in the pixel centre, so its extreme over the rectangle sits at the corner that the signs of
-                    // its gradient select, and the value computed THERE (with the operations of the scan) differs from any
-                    // pixel's computed value by at most the function's slope + 2^-51 (sum of |products|) <= 2^-51 Sa R:
-                    // margins of 2^-40 of the same magnitudes.
-                    const double xa = s1y >= 0.0 ? xlo : xhi, ya = s0y <= 0.0 ? ylo : yhi;                  // min u.x
-                    const double uxm = s0y * (ay - ya) - (ax - xa) * s1y;
-                    const double xb = s1x <= 0.0 ? xlo : xhi, yb = s0x >= 0.0 ? ylo : yhi;                  // min u.y
-                    const double uym = (ax - xb) * s1x - s0x * (ay - yb);
-                    const double gx = s1y - s1x, gy = s0x - s0y;                                           // gradient of u.x + u.y
-                    const double xc = gx >= 0.0 ? xhi : xlo, yc = gy >= 0.0 ? yhi : ylo;                    // max u.x + u.y
-                    const double usm = (s0y * (ay - yc) - (ax - xc) * s1y) + ((ax - xc) * s1x - s0x * (ay - yc));
-                    const double R = fabs(ax - xlo) + fabs(ay - ylo) + 16.0;                               // >= |A - pixel| (L1) on the rectangle
-                    const double ma = 0x1p-40 * ((fabs(s0y) + fabs(s1y)) * R) + 0x1p-1000;
-                    const double mb = 0x1p-40 * ((fabs(s0x) + fabs(s1x)) * R) + 0x1p-1000;
-                    // (depth)  every covered pixel's z is above the plane c0 + (ax - x) g1 + (ay - y) g2 (k_setup), whose minimum
-                    // over the rectangle again sits at a corner; if even that is not below the block's largest stored depth,
-                    // no pixel of the block passes the strict `<` of :165.  NaN compares false = keep.
-                    // The plane reaches below the triangle's own depths outside the triangle; a covered pixel also has b_i >= 0 and
-                    // b0 + b1 + b2 = 1 +- 2^-50, hence z >= min(z0, z1, z2) - 2^-40 max|z_i|, and the plane's values AT the three vertices
-                    // A, A + (s0y, s1y), A + (s0x, s1x) are z_i minus k_setup's margin (>= 2^-39 max|z_i| (R S/|u.z| + 1) with R >= S, which
-                    // also covers the roundings of these three evaluations): their minimum is below that bound.  The larger of the two
-                    // lower bounds counts.
-                    const double xz = g1 >= 0.0 ? xhi : xlo, yz = g2 >= 0.0 ? yhi : ylo;
-                    const double zpl = __builtin_fma(ax - xz, g1, __builtin_fma(ay - yz, g2, c0));
-                    const double zv = dmin(dmin(c0, __builtin_fma(-s0y, g1, __builtin_fma(-s1y, g2, c0))), __builtin_fma(-s0x, g1, __builtin_fma(-s1x, g2, c0)));
-                    if (uxm > ma || uym > mb || usm < uz - (ma + mb) || vmax(zpl, zv) >= zmaxb) keep = false;
+                if (keep) {
+                    const double2 q0 = pq0, q1 = pq1, q2 = pq2, q3 = pq3, q4 = pq4;
+                    const uint4 q5 = pq5;
+                    if (ALLWS || !(q5.w & TRGL_DL_LITERAL)) {
+                        const double ax = q0.x, ay = q0.y, s0x = q1.x, s0y = q1.y, s1x = q2.x, s1y = q2.y, c0 = q3.x, uz = q3.y, g1 = q4.x, g2 = q4.y;
+                        // pixel centres of (bbox n block): [xlo, xhi] x [ylo, yhi]
+                        const int bx0 = (int)(q5.x & 0xffffu), by0 = (int)(q5.x >> 16), bx1 = (int)(q5.y & 0xffffu), by1 = (int)(q5.y >> 16);
+                        const double xlo = (double)max(bx0, X0) + 0.5, xhi = (double)min(bx1, X0 + 7) + 0.5;
+                        const double ylo = (double)max(by0, Y0) + 0.5, yhi = (double)min(by1, Y0 + 7) + 0.5;
+                        // (edge)  a pixel is covered iff the rounded u.x <= 0, u.y <= 0 and u.x + u.y >= u.z (the sign form of :152);
+                        // each is affine in the pixel centre, so its extreme over the rectangle sits at the corner that the signs of
+                        // its gradient select, and the value computed THERE (with the operations of the scan) differs from any
+                        // pixel's computed value by at most the function's slope + 2^-51 (sum of |products|) <= 2^-51 Sa R:
+                        // margins of 2^-40 of the same magnitudes.
+                        const double xa = s1y >= 0.0 ? xlo : xhi, ya = s0y <= 0.0 ? ylo : yhi;                  // min u.x
+                        const double uxm = s0y * (ay - ya) - (ax - xa) * s1y;
+                        const double xb = s1x <= 0.0 ? xlo : xhi, yb = s0x >= 0.0 ? ylo : yhi;                  // min u.y
+                        const double uym = (ax - xb) * s1x - s0x * (ay - yb);
+                        const double gx = s1y - s1x, gy = s0x - s0y;                                           // gradient of u.x + u.y
+                        const double xc = gx >= 0.0 ? xhi : xlo, yc = gy >= 0.0 ? yhi : ylo;                    // max u.x + u.y
+                        const double usm = (s0y * (ay - yc) - (ax - xc) * s1y) + ((ax - xc) * s1x - s0x * (ay - yc));
+                        const double R = fabs(ax - xlo) + fabs(ay - ylo) + 16.0;                               // >= |A - pixel| (L1) on the rectangle
+                        const double ma = 0x1p-40 * ((fabs(s0y) + fabs(s1y)) * R) + 0x1p-1000;
+                        const double mb = 0x1p-40 * ((fabs(s0x) + fabs(s1x)) * R) + 0x1p-1000;
+                        // (depth)  every covered pixel's z is above the plane c0 + (ax - x) g1 + (ay - y) g2 (k_setup), whose minimum
+                        // over the rectangle again sits at a corner; if even that is not below the block's largest stored depth,
+                        // no pixel of the block passes the strict `<` of :165.  NaN compares false = keep.
+                        // The plane reaches below the triangle's own depths outside the triangle; a covered pixel also has b_i >= 0 and
+                        // b0 + b1 + b2 = 1 +- 2^-50, hence z >= min(z0, z1, z2) - 2^-40 max|z_i|, and the plane's values AT the three vertices
+                        // A, A + (s0y, s1y), A + (s0x, s1x) are z_i minus k_setup's margin (>= 2^-39 max|z_i| (R S/|u.z| + 1) with R >= S, which
+                        // also covers the roundings of these three evaluations): their minimum is below that bound.  The larger of the two
+                        // lower bounds counts.
+                        const double xz = g1 >= 0.0 ? xhi : xlo, yz = g2 >= 0.0 ? yhi : ylo;
+                        const double zpl = __builtin_fma(ax - xz, g1, __builtin_fma(ay - yz, g2, c0));
+                        const double zv = dmin(dmin(c0, __builtin_fma(-s0y, g1, __builtin_fma(-s1y, g2, c0))), __builtin_fma(-s0x, g1, __builtin_fma(-s1x, g2, c0)));
+                        if (uxm > ma || uym > mb || usm < uz - (ma + mb) || vmax(zpl, zv) >= zmaxb) keep = false;
+                    }
                 }
-            }
-            unsigned long long surv = __ballot(keep);
+            } else if (!can) break;
+            const unsigned long long surv = __ballot(keep);
+            const uint32_t tri = ptri;                   // the tested round's candidates (the survivors among them are visited below)
             TRGL_DBG(1, __popcll(surv));
-            TRGL_STAMP(12);        // cull round (ring read, gather, tests)
-            // ---- visits: the survivors in list order, constants through the scalar cache one visit ahead -------------------
-            // One visit = our_gl.cpp:147-152 for one triangle on this block, one pixel per lane, up to the coverage decision.
-            auto visit = [&](const TriScan& T, uint32_t tcur) {
-                // the lanes of `m` note (u.x, u.y, triangle): moves under the mask, in place
-                auto note = [&](unsigned long long m, double ux, double uy) {
-                    unsigned long long sv;
-                    asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\tv_mov_b64 %[px], %[ux]\n\tv_mov_b64 %[py], %[uy]\n\t"
-                                 "v_mov_b32 %[pt], %[t]\n\tv_mov_b64 %[puz], %[uz]\n\tv_mov_b64 %[pruz], %[ruz]\n\t"
-                                 "v_mov_b64 %[pz0], %[z0]\n\tv_mov_b64 %[pz1], %[z1]\n\tv_mov_b64 %[pz2], %[z2]\n\tv_mov_b32 %[pcd], %[cd]\n\ts_mov_b64 exec, %[sv]"
-                                 : [px] "+v"(S.pux), [py] "+v"(S.puy), [pt] "+v"(S.ptri), [sv] "=&s"(sv),
-                                   [puz] "+v"(S.puz), [pruz] "+v"(S.pruz), [pz0] "+v"(S.pz0), [pz1] "+v"(S.pz1), [pz2] "+v"(S.pz2), [pcd] "+v"(S.pcd)
-                                 : [ux] "v"(ux), [uy] "v"(uy), [t] "s"(tcur), [m] "s"(m), [cd] "s"(KIND == TRGL_SHADER_FLAT ? T.color : T.dl),
-                                   [uz] "s"(T.uz), [ruz] "s"(T.ruz), [z0] "s"(T.z0), [z1] "s"(T.z1), [z2] "s"(T.z2));
-                };
-                double ux, uy;
-                unsigned long long cm;                    // lanes with a covered pixel that can still win the z-test (wave-uniform)
-                unsigned long long both, sv, sx;          // ... that still hold a fragment of an earlier triangle; scratch
+            TRGL_STAMP(12);        // cull round (tests)
+            if (can) {
+                const uint32_t n = cnt < 64 ? cnt : 64;
+                __builtin_amdgcn_wave_barrier();
+                ptri = ring[(head + lane) & (RING - 1)];
+                __builtin_amdgcn_wave_barrier();
+                head += n; cnt -= n; pn = n;
+                if ((uint32_t)lane < n
 #ifdef TRGL_DEBUG_COUNTERS
-                unsigned long long am = 0;
+                    && ptri < fp.n_tris
 #endif
-                const uint32_t ext = T.by - T.bx;         // (hi >= lo in both 16-bit halves: no borrow)
-                if (ALLWS || !(T.dl & TRGL_DL_LITERAL)) {
-                    // The core of a visit is written out instruction by instruction: 19 vector + 4 scalar instructions, straight-line
-                    // but for one branch.  (From C++ the compiler builds it with exec-mask regions: zero-initialised phi registers,
-                    // save / restore pairs and a mask -> vector -> mask round trip for the ballot: ~30 vector + ~25 scalar.)  Every
-                    // vector instruction issues for all 64 lanes whether they matter or not, so nothing is masked: lanes outside
-                    // (bbox n block), hidden lanes and uncovered lanes only drop out of the final mask.
-                    //   NO test of the lane's pixel against the triangle's bbox (our_gl.cpp:130-133 only visits bbox pixels): a pixel centre
-                    //     outside floor(min) .. ceil(max) is at least half a pixel away from the triangle, and k_setup sends every triangle
-                    //     for which the roundings of u could bridge that (2^-40 S^2 R >= |u.z|) down the literal path below, which keeps the
-                    //     test.  Pixels beyond the image or outside the strip hold -inf and fail the depth comparison.
-                    //   barycentric(), our_gl.cpp:77-86: s0z = ax - x, s1z = ay - y (s0.xy, s1.xy and u.z hoisted into the record)
-                    //   depth first: zpl = fma(s0z, g1, fma(s1z, g2, c0)); a pixel with zpl >= its stored depth fails the z-test whatever
-                    //     its coverage (k_setup); NaN reads as keep.  No lane left: the visit ends here.
-                    //   u.x = s0y s1z - s0z s1y (geometry.h:145), u.y = s0z s1x - s0x s1z (:146), us = u.x + u.y, every product and sum
-                    //     rounded on its own as in the reference
-                    //   covered <=> !(us < u.z) && !(u.y > 0) && !(u.x > 0): u.z < 0 and nothing can over/underflow, so the signs of the
-                    //     quotients of :85 are known without dividing ("exactness"); max(u.x, u.y) > 0 <=> one of them is.
-                    double s0z, s1z, ta, tb2;
-#ifdef TRGL_DEBUG_COUNTERS
-                    am = __ballot(__builtin_bit_cast(uint32_t, __builtin_elementwise_max(S.xy - __builtin_bit_cast(us2, T.bx), __builtin_bit_cast(us2, ext))) == ext);
-#endif
-                    // (`asm goto` would let the exits of this block skip the test of `both` behind it; this compiler's AMDGPU back end
-                    // loses the block's contents when it has branch targets outside, so the exits set both = 0 and fall out.)
-                    asm volatile(
-                        "v_add_f64 %[s0z], %[ax], -%[pxc]\n\t"
-                        "v_add_f64 %[s1z], %[ay], -%[pyc]\n\t"
-                        "v_mov_b64 %[ta], %[c0]\n\t"
-                        "v_fmac_f64 %[ta], %[g2], %[s1z]\n\t"
-                        "v_fmac_f64 %[ta], %[g1], %[s0z]\n\t"
-                        "v_cmp_nge_f64_e32 vcc, %[ta], %[z]\n\t"
-#ifdef TRGL_DEBUG_COUNTERS
-                        "s_mov_b64 %[cm], 0\n\t"
-#endif
-                        "s_cbranch_vccz .Lvisit_end%=\n\t"
-                        "v_mul_f64 %[ta], %[s0y], %[s1z]\n\t"
-                        "v_mul_f64 %[tb], %[s1y], %[s0z]\n\t"
-                        "v_add_f64 %[ux], %[ta], -%[tb]\n\t"
-                        "v_mul_f64 %[ta], %[s1x], %[s0z]\n\t"
-                        "v_mul_f64 %[tb], %[s0x], %[s1z]\n\t"
-                        "v_add_f64 %[uy], %[ta], -%[tb]\n\t"
-                        "v_add_f64 %[ta], %[ux], %[uy]\n\t"
-                        "v_max_f64 %[tb], %[ux], %[uy]\n\t"
-                        "v_cmp_nlt_f64_e64 %[cm], %[ta], %[uz]\n\t"
-                        "s_and_b64 %[cm], %[cm], vcc\n\t"
-                        "v_cmp_nlt_f64_e32 vcc, 0, %[tb]\n\t"
-                        "s_and_b64 %[cm], %[cm], vcc\n\t"
-                        "s_cbranch_scc0 .Lvisit_end%=\n\t"
-                        // covered lanes: those that hold no fragment note (u.x, u.y, triangle) at once, in place (moves under the mask);
-                        // `both` = the covered lanes that still hold one (the code behind the block resolves first, then notes theirs)
-                        "s_andn2_b64 %[sv], %[cm], %[pend]\n\t"
-                        "s_cbranch_scc0 .Lvisit_noted%=\n\t"
-                        "s_mov_b64 %[sx], exec\n\t"
-                        "s_mov_b64 exec, %[sv]\n\t"
-                        "v_mov_b64 %[pux], %[ux]\n\t"
-                        "v_mov_b64 %[puy], %[uy]\n\t"
-                        "v_mov_b32 %[ptri], %[tcur]\n\t"
-                        "v_mov_b64 %[puz], %[uz]\n\t"
-                        "v_mov_b64 %[pruz], %[ruz]\n\t"
-                        "v_mov_b64 %[pz0], %[z0]\n\t"
-                        "v_mov_b64 %[pz1], %[z1]\n\t"
-                        "v_mov_b64 %[pz2], %[z2]\n\t"
-                        "v_mov_b32 %[pcd], %[cd]\n\t"
-                        "s_mov_b64 exec, %[sx]\n"
-                        ".Lvisit_noted%=:\n\t"
-                        "s_or_b64 %[pend], %[pend], %[cm]\n\t"
-                        "s_xor_b64 %[both], %[cm], %[sv]\n\t"
-                        "s_branch .Lvisit_done%=\n"
-                        ".Lvisit_end%=:\n\t"
-                        "s_mov_b64 %[both], 0\n"
-                        ".Lvisit_done%=:"
-                        : [cm] "=&s"(cm), [ux] "=&v"(ux), [uy] "=&v"(uy), [s0z] "=&v"(s0z), [s1z] "=&v"(s1z), [ta] "=&v"(ta), [tb] "=&v"(tb2),
-                          [both] "=&s"(both), [sv] "=&s"(sv), [sx] "=&s"(sx), [pend] "+s"(pend), [pux] "+v"(S.pux), [puy] "+v"(S.puy), [ptri] "+v"(S.ptri),
-                          [puz] "+v"(S.puz), [pruz] "+v"(S.pruz), [pz0] "+v"(S.pz0), [pz1] "+v"(S.pz1), [pz2] "+v"(S.pz2), [pcd] "+v"(S.pcd)
-                        : [pxc] "v"(S.pxc), [pyc] "v"(S.pyc), [z] "v"(S.z), [tcur] "s"(tcur),
-                          [ax] "s"(T.ax), [ay] "s"(T.ay), [c0] "s"(T.c0), [g1] "s"(T.g1), [g2] "s"(T.g2),
-                          [s0x] "s"(T.s0x), [s0y] "s"(T.s0y), [s1x] "s"(T.s1x), [s1y] "s"(T.s1y), [uz] "s"(T.uz),
-                          [ruz] "s"(T.ruz), [z0] "s"(T.z0), [z1] "s"(T.z1), [z2] "s"(T.z2), [cd] "s"(KIND == TRGL_SHADER_FLAT ? T.color : T.dl)
-                        : "vcc", "scc");
-                } else {
-                    // a triangle that is not well scaled: the same visit from C++, coverage from the literal quotients of :85
-                    const us2 off = S.xy - __builtin_bit_cast(us2, T.bx);
-                    const bool act = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(off, __builtin_bit_cast(us2, ext))) == ext;
-                    const double s0z = T.ax - S.pxc, s1z = T.ay - S.pyc;
-                    const double zpl = __builtin_fma(s0z, T.g1, __builtin_fma(s1z, T.g2, T.c0));
-                    ux = T.s0y * s1z - s0z * T.s1y;                               // geometry.h:145
-                    uy = s0z * T.s1x - T.s0x * s1z;                               // geometry.h:146
-                    const double us = ux + uy;
-                    const double b0 = 1.0 - us / T.uz, b1 = uy / T.uz, b2 = ux / T.uz;      // :85, as written
-                    cm = __ballot(act && !(zpl >= S.z) && !(b0 < 0 || b1 < 0 || b2 < 0));  // :152
-#ifdef TRGL_DEBUG_COUNTERS
-                    am = __ballot(act);
-#endif
-                    both = cm & pend;
-                    note(cm & ~pend, ux, uy);
-                    pend |= cm;
+                    ) {
+                    const double2* q = reinterpret_cast<const double2*>(recs + ptri);
+                    pq0 = q[0]; pq1 = q[1]; pq2 = q[2]; pq3 = q[3]; pq4 = q[4];
+                    pq5 = reinterpret_cast<const uint4*>(q)[7];
                 }
-                TRGL_DBG(2, tcur < fp.n_tris ? 1 : 0); TRGL_DBG(3, __popcll(am)); TRGL_DBG(4, cm ? 1 : 0); TRGL_DBG(5, __popcll(cm));
-                if (both) {
-                    // Some covered lanes still hold a fragment of an earlier triangle, which has to be resolved first (submission
-                    // order per pixel).  Everything that can go goes in that one pass: the old fragments of all noted lanes AND the
-                    // new ones of the lanes that held none (`pend` holds them already); only the conflicting lanes' new fragments
-                    // stay noted afterwards.
-                    resolve<KIND, ALLWS, DEFERRED>(S, pend, recs, recs_w, draws, stats, zero_locked);
-                    note(both, ux, uy);
-                    asm volatile("s_mov_b64 %0, %1" : "+s"(pend) : "s"(both));      // pend = both, in the register that holds it
-                }
-            };
+            } else pn = 0;
             if (surv) {
                 // The survivors move to lanes 0 .. ns - 1 (through LDS, order kept), so that the visit loop counts instead of peeling bits
                 // off a 64-bit mask: 2 scalar instructions per visit instead of 8 - the scalar unit, one instruction per cycle for the
