@@ -271,18 +271,22 @@ __device__ __forceinline__ double div_by_uz(double a, double uz, double ruz) {
 //  2. cull         Whenever 64 candidates are waiting (or the list ends): lane = candidate.  The lane reads 96 B of its
 //                  triangle's record and drops the triangle when one of the three edge functions excludes every pixel of
 //                  (bbox n block) or when its depth plane cannot get below the block's largest stored depth (both tests in fp64
-//                  with margins 2^10 times the rounding they cover; "edge" and "depth" below).
-//  3. visits       The survivors, in list order.  The triangle's constants arrive as wave-uniform values through the scalar
-//                  cache (s_load_dwordx16 + dwordx8 of the record, requested one visit ahead), so the vector instructions take
-//                  them as scalar operands and no vector register holds a per-triangle constant.  Per visit, one pixel per lane:
-//                  lanes of (bbox n block) [a 64-bit mask built with scalar instructions], depth plane against the lane's
-//                  stored depth, barycentric() + sign coverage test.  That is where a visit ENDS: the covered lanes only note
-//                  (u.x, u.y, triangle) in registers ...
+//                  with margins 2^10 times the rounding they cover; "edge" and "depth" below).  The gather of a round is requested
+//                  one round ahead: between the test of the round before it and the visits of that round's survivors.
+//  3. visits       The survivors (compacted into the low lanes), in list order.  The triangle's constants arrive as wave-uniform
+//                  values through the scalar cache (two s_load_dwordx16 = the whole record, requested one visit ahead), so the
+//                  vector instructions take them as scalar operands and no vector register holds a per-triangle constant.
+//                  Per visit, one pixel per lane: depth plane against the lane's stored depth, barycentric() + sign coverage test
+//                  (no bbox test: k_setup sends the slivers that would need one down the literal path).  That is where a visit
+//                  ENDS: the covered lanes only note (u.x, u.y, triangle) in registers ...
 //  4. resolve      ... and the three divisions of our_gl.cpp:85, the depth of :156-158, the z-test and the fragment run later
-//                  for ALL noted lanes at once, each lane with its own triangle (per-lane gathers of 48 B of the record):
-//                  when a visit covers a lane that still holds a note (so that every pixel sees its fragments in submission
-//                  order) and at the end of the list.  Small triangles cover a few lanes each; resolving several of them
-//                  together is what fills the lanes of the most expensive part of the pixel loop.
+//                  for ALL noted lanes at once, each lane with its own triangle (its u.z, 1/u.z, depths and colour were noted too:
+//                  no memory access): when a visit covers a lane that still holds a note (so that every pixel sees its
+//                  fragments in submission order) and at the end of the list.  Small triangles cover a few lanes each;
+//                  resolving several of them together is what fills the lanes of the most expensive part of the pixel loop.
+//
+// The scalar unit issues one instruction per cycle for the four SIMDs of a CU and was as busy as the vector units in the first
+// version of this kernel: the visit loop is written to need few scalar instructions (k_raster).
 //
 // Exactness: as before, operation for operation in fp64 with contraction off; sign coverage + FMA division by u.z for
 // well-scaled triangles ("exactness"), the literal divisions for the others (`dl` bit 31).
@@ -511,7 +515,7 @@ __device__ __forceinline__ void clear_rows(const FrameParams& fp, int lane, int 
 //   bits 0-23 tile, bits 24-25 row of blocks inside the tile, bit 31: the tile has no triangles and is only cleared
 #define TRGL_ITEM_CLEAR 0x80000000u
 #ifndef TRGL_RASTER_WAVES
-#define TRGL_RASTER_WAVES 5        // waves per SIMD the register allocation of k_raster aims at (96 vector registers; 80 spill: measured slower)
+#define TRGL_RASTER_WAVES 5        // waves per SIMD the register allocation of k_raster aims at (96 vector registers; 6 waves = 80 registers spill 8 dwords per list step: 2 % slower)
 #endif
 
 // BPP: the framebuffer's bytes per pixel when the kernel is compiled for one (3 or 4, FLAT only), 0 = read from FrameParams
@@ -612,8 +616,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
 #endif
         const uint32_t ext = T.by - T.bx;         // (hi >= lo in both 16-bit halves: no borrow)
         if (ALLWS || !(T.dl & TRGL_DL_LITERAL)) {
-            // The core of a visit is written out instruction by instruction: 19 vector + 4 scalar instructions, straight-line
-            // but for one branch.  (From C++ the compiler builds it with exec-mask regions: zero-initialised phi registers,
+            // The core of a visit is written out instruction by instruction: 16 vector instructions, straight-line
+            // but for two exits.  (From C++ the compiler builds it with exec-mask regions: zero-initialised phi registers,
             // save / restore pairs and a mask -> vector -> mask round trip for the ballot: ~30 vector + ~25 scalar.)  Every
             // vector instruction issues for all 64 lanes whether they matter or not, so nothing is masked: lanes outside
             // (bbox n block), hidden lanes and uncovered lanes only drop out of the final mask.
