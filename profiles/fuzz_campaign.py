@@ -1,6 +1,6 @@
 """One-off differential campaign: the two randomised GPU-vs-oracle tests of tests/test_gpu_parity.py with many more seeds
 than the suite runs, the extreme-depth scenes and the GOURAUD / PHONG soups
-(python profiles/fuzz_campaign.py [n_fuzz] [n_adversarial] [n_depth] [n_gouraud] [n_phong])."""
+(python profiles/fuzz_campaign.py [n_fuzz] [n_adversarial] [n_depth] [n_gouraud] [n_phong] [n_large])."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,6 +10,7 @@ na = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 nd = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 ng = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 np_ = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+nl = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 t0 = time.time(); bad = []
 for s in range(12, 12 + nf):
     try: T.test_fuzz_flat_scenes_against_oracle(s)
@@ -29,5 +30,9 @@ for s in range(4, 4 + ng):
 for s in range(4, 4 + np_):
     try: T.test_fuzz_phong_soup_against_oracle(s)
     except AssertionError as e: bad.append(("phong", s, str(e)[:80]))
+for s in range(4, 4 + nl):
+    try: T.test_depth_bound_in_the_pair_on_large_triangles(s)
+    except AssertionError as e: bad.append(("large", s, str(e)[:80]))
+if nl: print(f"{nl} scenes of large triangles done, {len(bad)} mismatching so far, {time.time() - t0:.0f} s", flush=True)
 if ng or np_: print(f"{ng} gouraud + {np_} phong soups done, {len(bad)} mismatching so far, {time.time() - t0:.0f} s", flush=True)
 print(f"{nf} fuzz + {na} adversarial + {nd} extreme-depth scenes in {time.time() - t0:.0f} s: {len(bad)} mismatching", bad[:5])

@@ -874,3 +874,42 @@ def test_interleaved_rank_without_rows_draws_nothing_and_stays_usable():
     o = orc.Oracle(W, H, 3)
     o.draw(orc.FLAT, clip, colors=col)
     assert np.array_equal(fb, o.fb) and np.array_equal(z.view(np.uint64), o.z.view(np.uint64)) and st == o.stats
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_depth_bound_in_the_pair_on_large_triangles(seed):
+    """A flush that holds triangles of 64 pixels and more lets k_raster's list steps drop entries by the 7-bit depth bound that rides in
+    the pair's triangle word (TRGL_VAL_ZQ): 4000 triangles of 20 - 300 px on 320 x 200, depth complexity in the hundreds, so that
+    nearly every later entry is occluded - and has to be dropped ONLY then.  A third of them get a vertex depth outside [-1, 1]
+    (bound 0 = says nothing), every fifth is nearly flat in depth (bound as tight as the 1/64 grid allows), all on top of small
+    triangles that share the tiles.  z bits, colours and counters must equal the oracle's."""
+    W, H = 320, 200
+    big, bcol = scenes.random_triangles(4000, W, H, seed=8100 + seed, rmin=20, rmax=300)
+    small, scol = scenes.random_triangles(6000, W, H, seed=8200 + seed, rmin=1, rmax=12)
+    rng = scenes.SplitMix64(8300 + seed)
+    u = rng.uniform(4000 * 2).reshape(4000, 2)
+    big = big.copy()
+    for i in range(4000):
+        if i % 3 == 0:
+            big[i, 4 * (i % 3) + 2] = -1.0 - 3.0 * u[i, 0]           # one vertex in front of the near plane
+        if i % 5 == 0:
+            z0 = 2.0 * u[i, 1] - 1.0
+            for v in range(3):
+                big[i, 4 * v + 2] = z0 + 1e-4 * v
+    clip = np.concatenate([small[:3000], big[:2000], small[3000:], big[2000:]])
+    col = np.concatenate([scol[:3000], bcol[:2000], scol[3000:], bcol[2000:]])
+    with Context(W, H, 3) as ctx:
+        ctx.draw(FLAT, clip, colors=col)
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+        # the same scene in two flushes, the second starting from the depths of the first
+        ctx.clear()
+        ctx.draw(FLAT, clip[:5000], colors=col[:5000]); ctx.flush()
+        ctx.draw(FLAT, clip[5000:], colors=col[5000:])
+        fb2, z2 = ctx.read_framebuffer(), ctx.read_zbuffer()
+    o = orc.Oracle(W, H, 3)
+    o.draw(orc.FLAT, clip, colors=col)
+    assert np.array_equal(z.view(np.uint64), o.z.view(np.uint64))
+    assert np.array_equal(fb, o.fb)
+    assert st == o.stats
+    assert np.array_equal(z2.view(np.uint64), o.z.view(np.uint64)) and np.array_equal(fb2, o.fb)

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
 
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;   // contribution to bbox stats
     uint32_t ntiles = 0;
+    bool large = false;
     uint2 tb = make_uint2(0, 0);
     TriRec r;
     {
@@ -190,6 +191,20 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
                 // the 4 x 4 mask of the tile's blocks that the box reaches
                 tb = make_uint2(((uint32_t)bx0 >> TRGL_BLOCK_LOG2) | (((uint32_t)y_lo >> TRGL_BLOCK_LOG2) << 16),
                                 ((uint32_t)bx1 >> TRGL_BLOCK_LOG2) | (((uint32_t)y_hi >> TRGL_BLOCK_LOG2) << 16));
+                // A 7-bit lower bound of the triangle's depths rides with every pair (in the spare bits of its triangle word, k_expand):
+                // every covered pixel has z above the depth plane's smallest value at the three vertices (k_raster's cull explains
+                // why), zv, hence z >= -1 + zq / 64 for zq = floor((zv + 1) 64 - 2^-20).  In the spare bits of the box: block
+                // coordinates stay below 2^13.  A flush that holds large triangles (`large`) makes k_raster's list steps use it: an
+                // entry whose bound is not below the block's largest depth never becomes a candidate - no gather, no test.
+                uint32_t zq = 0;
+                if (r.c0 > -__builtin_inf()) {
+                    const double zv = dmin3(r.c0, __builtin_fma(-r.s0y, r.g1, __builtin_fma(-r.s1y, r.g2, r.c0)),
+                                            __builtin_fma(-r.s0x, r.g1, __builtin_fma(-r.s1x, r.g2, r.c0)));
+                    const double t = (zv + 1.0) * 64.0 - 0x1p-20;
+                    if (t >= 1.0) zq = t >= 127.0 ? 127u : (uint32_t)x86_cvttsd2si(floor(t));
+                }
+                tb.x |= (zq & 7u) << 13; tb.y |= ((zq >> 3) & 7u) << 13; tb.y |= (zq >> 6) << 29;
+                large = bx1 - bx0 >= 64 || y_hi - y_lo >= 64;
             }
         }
         cnt[d.first + i] = ntiles;
@@ -234,6 +249,8 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const D
     {
         const unsigned long long lit = __ballot(ntiles != 0 && r.ruz == 0.0);
         if (lit && lane == 0) atomicAdd(&stats->literal_tris, (unsigned long long)__popcll(lit));
+        const unsigned long long lrg = __ballot(large);
+        if (lrg && lane == 0) atomicAdd(&stats->large_tris, (unsigned long long)__popcll(lrg));
     }
     // bbox stats (our_gl.cpp:138-141): one set of atomics per wave
     int wx0 = wave_min_i(bx0), wy0 = wave_min_i(by0), wx1 = wave_max_i(bx1), wy1 = wave_max_i(by1);
@@ -360,14 +377,15 @@ __global__ __launch_bounds__(256) void k_expand(FrameParams fp, uint32_t first, 
     constexpr uint32_t SMALL = 8;
     if (c && c <= SMALL) {
         // row-major walk with running counters instead of a division and a modulo per pair
-        const uint32_t qx0 = tb.x & 0xffff, qy0 = tb.x >> 16, qx1 = tb.y & 0xffff, qy1 = tb.y >> 16;
+        const uint32_t qx0 = tb.x & 0x1fff, qy0 = (tb.x >> 16) & 0x1fff, qx1 = tb.y & 0x1fff, qy1 = (tb.y >> 16) & 0x1fff;
+        const uint32_t iz = i | ((((tb.x >> 13) & 7u) | (((tb.y >> 13) & 7u) << 3) | ((tb.y >> 29) << 6)) << 25);      // TRGL_VAL_TRI | TRGL_VAL_ZQ
         const uint32_t tx0 = qx0 >> 2, ty0 = qy0 >> 2, tx1 = qx1 >> 2;
         uint32_t tx = tx0, row = 0;
         uint32_t ty = fp.il_tiles ? (uint32_t)il_nth_owned_from(fp, (int)ty0, 0) : ty0;
         for (uint32_t k = 0; k < c; ++k) {
             const K key = (K)(ty * tiles_x + tx);
             const uint16_t m = (uint16_t)tile_block_mask(tx, ty, qx0, qy0, qx1, qy1);
-            if (staged) { s_k[o + k] = key; s_v[o + k] = i; s_m[o + k] = m; } else { kdst[o + k] = key; vdst[o + k] = i; mdst[o + k] = m; }
+            if (staged) { s_k[o + k] = key; s_v[o + k] = iz; s_m[o + k] = m; } else { kdst[o + k] = key; vdst[o + k] = iz; mdst[o + k] = m; }
             if (++tx > tx1) { tx = tx0; ++row; ty = fp.il_tiles ? (uint32_t)il_nth_owned_from(fp, (int)ty0, (int)row) : ty0 + row; }
         }
     }
@@ -378,7 +396,8 @@ __global__ __launch_bounds__(256) void k_expand(FrameParams fp, uint32_t first, 
         big &= big - 1;
         uint32_t cc = __shfl(c, src), oo = __shfl(o, src), ii = __shfl(i, src);
         uint32_t bx = __shfl(tb.x, src), by = __shfl(tb.y, src);
-        const uint32_t qx0 = bx & 0xffff, qy0 = bx >> 16, qx1 = by & 0xffff, qy1 = by >> 16;
+        const uint32_t qx0 = bx & 0x1fff, qy0 = (bx >> 16) & 0x1fff, qx1 = by & 0x1fff, qy1 = (by >> 16) & 0x1fff;
+        ii |= (((bx >> 13) & 7u) | (((by >> 13) & 7u) << 3) | ((by >> 29) << 6)) << 25;
         uint32_t tx0 = qx0 >> 2, ty0 = qy0 >> 2, tx1 = qx1 >> 2;
         uint32_t wdt = tx1 - tx0 + 1;
         for (uint32_t k = lane; k < cc; k += 64) {

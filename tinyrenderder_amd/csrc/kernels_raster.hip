@@ -749,6 +749,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                 const uint32_t v = (0xfu << lo) & (0xfu >> (4u - hi));
                 c0 &= v; c1 &= v >> 1; c2 &= v >> 2; c3 &= v >> 3;
             }
+            if (fp.zq_cull) {
+                // The flush holds large triangles: an entry whose depth bound (7 bits in its triangle word, k_setup) is not below the
+                // block's largest stored depth cannot put a fragment into this block - it never becomes a candidate.  qb: the depth
+                // rounded UP to the bound's grid (a float rounded up, then 2^-10 of a step more for the roundings here; 128 = nothing
+                // stored yet).  Occluded triangles of frames with a high depth complexity die here, 256 entries per step, without
+                // their records being touched.
+                const float zmb = wave_max_f32(f32_up(S.z));
+                const float tq = (zmb + 1.0f) * 64.0f + 0x1p-10f;
+                const uint32_t qb = !(tq < 128.0f) ? 128u : (tq <= 1.0f ? 1u : (uint32_t)__builtin_ceilf(tq));      // (>= 1: zq = 0 says nothing)
+                c0 = TRGL_VAL_ZQ(tri_c.x) < qb ? c0 : 0u; c1 = TRGL_VAL_ZQ(tri_c.y) < qb ? c1 : 0u;
+                c2 = TRGL_VAL_ZQ(tri_c.z) < qb ? c2 : 0u; c3 = TRGL_VAL_ZQ(tri_c.w) < qb ? c3 : 0u;
+            }
             const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1), b2 = __ballot(c2), b3 = __ballot(c3);
             if (b0 | b1 | b2 | b3) {
                 uint32_t pos = head + cnt;
@@ -768,7 +780,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                     const uint32_t trs[4] = { tri_c.x, tri_c.y, tri_c.z, tri_c.w };
                     const uint32_t cs[4] = { c0, c1, c2, c3 };
                     for (int j = 0; j < 4; ++j)
-                        if (cs[j] && trs[j] >= fp.n_tris && atomicCAS(&stats->dbg[10], 0ull, 1ull) == 0ull) {
+                        if (cs[j] && TRGL_VAL_TRI(trs[j]) >= fp.n_tris && atomicCAS(&stats->dbg[10], 0ull, 1ull) == 0ull) {
                             stats->dbg[11] = ((unsigned long long)(p0 + 4u * (uint32_t)lane + (uint32_t)j) << 32) | trs[j];
                             stats->dbg[12] = ((unsigned long long)beg << 32) | end;
                             stats->dbg[13] = ((unsigned long long)(uint32_t)t << 32) | (uint32_t)kblk;
@@ -845,7 +857,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
             if (can) {
                 const uint32_t n = cnt < 64 ? cnt : 64;
                 __builtin_amdgcn_wave_barrier();
-                ptri = ring[(head + lane) & (RING - 1)];
+                ptri = TRGL_VAL_TRI(ring[(head + lane) & (RING - 1)]);
                 __builtin_amdgcn_wave_barrier();
                 head += n; cnt -= n; pn = n;
                 if ((uint32_t)lane < n
@@ -1203,7 +1215,7 @@ __global__ __launch_bounds__(1024) void k_fold_stats(DevStats* __restrict__ s, u
             s->zero_sign = s->zero_neg_key < s->zero_pos_key ? 1u : 0u;
             s->zero_locked = 1u;
         }
-        s->literal_tris = 0;                       // counted per flush (k_setup)
+        s->literal_tris = 0; s->large_tris = 0;    // counted per flush (k_setup)
         s->zero_pos_key = TRGL_ZERO_KEY_EMPTY;
         s->zero_neg_key = TRGL_ZERO_KEY_EMPTY;
         n_items[0] = 0;         // every block read it before its atomic above; k_make_items of the next flush appends from 0

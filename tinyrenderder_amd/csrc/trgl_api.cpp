@@ -111,7 +111,7 @@ static int reset_dev_stats(trgl_ctx* c) {
     s.zmin_key = zkey_host(std::numeric_limits<double>::infinity());
     s.zmax_key = zkey_host(-std::numeric_limits<double>::infinity());
     s.min_x = INT32_MAX; s.min_y = INT32_MAX; s.max_x = INT32_MIN; s.max_y = INT32_MIN;
-    s.pairs_total = 0; s.literal_tris = 0; s.reserved0 = 0;
+    s.pairs_total = 0; s.literal_tris = 0; s.large_tris = 0;
     s.zero_pos_key = s.zero_neg_key = TRGL_ZERO_KEY_EMPTY;
     s.zero_locked = 0; s.zero_sign = 0;
     for (int k = 0; k < 16; ++k) s.dbg[k] = 0;
@@ -546,7 +546,7 @@ int trgl_flush_begin(trgl_ctx* c) {
         }
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
         launch_chunk_spine(s, c->blk_sums, nblk, c->chunk_off, &c->stats_dev->pairs_total);
-        HIPCHK(c, hipMemcpyAsync(&c->stats_pinned->pairs_total, &c->stats_dev->pairs_total, 16, hipMemcpyDeviceToHost, s));   // + literal_tris
+        HIPCHK(c, hipMemcpyAsync(&c->stats_pinned->pairs_total, &c->stats_dev->pairs_total, 24, hipMemcpyDeviceToHost, s));   // + literal_tris, large_tris
         HIPCHK(c, hipEventRecord(c->ev_pairs, s));
         HIPCHK(c, hipMemsetAsync(c->tile_start, 0, ntiles * 8, s));                // tile_start and tile_end
         cap = (uint32_t)c->cap_pairs;
@@ -567,7 +567,7 @@ int trgl_flush_end(trgl_ctx* c) {
     c->rp.active = false;
     int r;
     hipStream_t s = c->stream;
-    const FrameParams fp = c->rp.fp;
+    FrameParams fp = c->rp.fp;
     const int flush_kind = c->rp.flush_kind;
     int cur = c->rp.cur;
     const uint64_t N = c->rp.N;
@@ -598,6 +598,7 @@ int trgl_flush_end(trgl_ctx* c) {
     if ((r = grow(c, c->item_stats, c->cap_item_stats, ((size_t)max_items + 64) * 4))) return r;
     // k_setup counted the triangles that are not well scaled (it came over with the pair count): without any, the kernel without the literal path
     const bool all_well_scaled = N == 0 || c->stats_pinned->literal_tris == 0;
+    fp.zq_cull = (N != 0 && c->stats_pinned->large_tris != 0) ? 1 : 0;      // (k_setup counted them; the count came over with the pair count)
     if (std::getenv("TRGL_DEBUG_PTRS")) {        // diagnostics: where the buffers of this flush live
         std::fprintf(stderr, "trgl ptrs: fb %p +%zu  zb %p +%zu  recs %p +%zu  recs_w %p  vals %p bmask %p cap_pairs %zu P %u  items %p cap %zu  item_stats %p  tile_start %p  N %llu max_items %u\n",
                      (void*)c->fb, (size_t)c->W * c->H * c->bpp, (void*)c->zb, (size_t)c->W * c->H * 8, (const void*)recs_arg, c->cap_tris * sizeof(TriRec), (void*)c->recs_w,

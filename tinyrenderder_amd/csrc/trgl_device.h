@@ -41,6 +41,10 @@ struct alignas(128) TriRec {
 static_assert(sizeof(TriRec) == 128, "TriRec must be one 128-B line");
 #define TRGL_DRAW_MAX_TRIS (1u << 24)   // triangles per DrawDesc; trgl_draw splits larger submissions
 #define TRGL_FLUSH_MAX_TRIS ((1u << 25) - 1u)  // triangles per flush: k_raster addresses a record (and the one behind the last) as base + (index << 7) with a 32-bit scalar offset
+// A pair's triangle word: index in the flush (25 bits, TRGL_FLUSH_MAX_TRIS) | a 7-bit lower bound of the triangle's depths,
+// zq: every covered pixel has z >= -1 + zq / 64 (k_setup; 0 = no bound).
+#define TRGL_VAL_TRI(v)   ((v) & 0x1ffffffu)
+#define TRGL_VAL_ZQ(v)    ((v) >> 25)
 #define TRGL_DL_LITERAL   0x80000000u
 #define TRGL_DL_DRAW(dl)  (((dl) >> 24) & (TRGL_MAX_DRAWS - 1))
 #define TRGL_DL_LOCAL(dl) ((dl) & 0xffffffu)
@@ -75,7 +79,8 @@ struct DevStats {
     unsigned long long pairs_total;      // written by the scan spine (implementation traffic)
     unsigned long long literal_tris;     // triangles of the flush in flight that are not "well scaled" (k_setup adds, k_fold_stats clears); copied to the
                                          // host together with pairs_total: a flush without any runs the raster kernel that has no literal path
-    unsigned long long reserved0;
+    unsigned long long large_tris;       // ... whose bbox is at least 64 pixels wide or high (k_setup adds, k_fold_stats clears): a flush with any lets the list steps of
+                                         // k_raster drop entries by the depth bound that rides in the pair (TRGL_VAL_ZQ)
     // std::min/std::max keep the FIRST of two equal values (our_gl.cpp:197-198), and +0.0 == -0.0:
     // when the z range ends in a zero its sign is that of the first zero written, in the reference's
     // order (triangle, x, y).  Keys = tri<<32 | x<<16 | y of the first +0 / -0 fragment of this flush.
@@ -103,6 +108,7 @@ struct FrameParams {
                                       // il_world contexts, this one takes band number == il_rank (mod il_world); il_tiles = 0: the strip above
     uint32_t n_tris;                  // triangles of the flush (diagnostic builds check list entries against it)
     int32_t  init_from_clear;         // 1: tiles start from the clear values, not from HBM
+    int32_t  zq_cull;                 // 1: the flush holds large triangles - k_raster's list steps compare TRGL_VAL_ZQ with the block's largest depth
     uint32_t clear_color;             // packed BGRA
     double   clear_z;
     double   vp[8];                   // rows 0 and 1 of the Viewport matrix (our_gl.cpp:117-121)
