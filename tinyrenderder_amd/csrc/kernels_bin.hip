@@ -368,8 +368,15 @@ __global__ __launch_bounds__(256) void k_expand(FrameParams fp, uint32_t first, 
     const uint32_t blk = blk_base + blockIdx.x;
     uint32_t c = 0; uint2 tb = make_uint2(0, 0);
     if (local < n) { c = cnt[i]; if (c) tb = tilebox[i]; }
-    uint32_t base = chunk_off[blk / EXPAND_CHUNK];
-    for (uint32_t q = blk - blk % EXPAND_CHUNK; q < blk; ++q) base += blk_sums[q];      // wave-uniform loads
+    // pairs before this block = those before its chunk of 16 blocks (k_chunk_spine) + the sums of the blocks before it inside the chunk:
+    // ONE load by up to 15 lanes and four butterfly steps (a loop of up to 15 dependent wave-uniform loads cost ~1 us each)
+    uint32_t base;
+    {
+        const uint32_t q0 = blk - blk % EXPAND_CHUNK, l = threadIdx.x & 63u;
+        uint32_t part = l < blk - q0 ? blk_sums[q0 + l] : 0u;
+        for (int o = 8; o; o >>= 1) part += __shfl_xor(part, o);
+        base = chunk_off[blk / EXPAND_CHUNK] + (uint32_t)__builtin_amdgcn_readfirstlane((int)part);
+    }
     uint32_t tot;
     const uint32_t o = block_excl_scan(c, smem, &tot);         // offset inside the block's run of pairs
     const bool staged = tot <= EXPAND_STAGE;                   // block-uniform
