@@ -174,7 +174,9 @@ int trgl_rccl_comm_destroy(void* nccl_comm);
  *   varyings : n x K doubles (K by kind, above) or NULL when K = 0
  *   colors   : n x uint32 (b | g<<8 | r<<16 | a<<24) for FLAT/GOURAUD, else NULL
  * Triangles are drawn in array order after everything submitted earlier (submission order is
- * observable: z ties keep the earlier triangle, our_gl.cpp:165). */
+ * observable: z ties keep the earlier triangle, our_gl.cpp:165).
+ * n is not limited by the batching inside: a submission is cut into draws of 2^24 triangles and a new flush is
+ * started before the 2^25-th triangle of one (neither shows in the frame or in the counters). */
 int trgl_draw(trgl_ctx* ctx, int shader_kind, const trgl_uniforms* uniforms,
               const double* clip, const double* varyings, const uint32_t* colors,
               uint64_t n, int mem_kind);
