@@ -816,37 +816,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                     const uint4 q5 = pq5;
                     if (ALLWS || !(q5.w & TRGL_DL_LITERAL)) {
                         const double ax = q0.x, ay = q0.y, s0x = q1.x, s0y = q1.y, s1x = q2.x, s1y = q2.y, c0 = q3.x, uz = q3.y, g1 = q4.x, g2 = q4.y;
-                        // pixel centres of (bbox n block): [xlo, xhi] x [ylo, yhi]
+                        // pixel centres of (bbox n block): the rectangle with centre (xm, ym) and half-widths (xh, yh)
                         const int bx0 = (int)(q5.x & 0xffffu), by0 = (int)(q5.x >> 16), bx1 = (int)(q5.y & 0xffffu), by1 = (int)(q5.y >> 16);
-                        const double xlo = (double)max(bx0, X0) + 0.5, xhi = (double)min(bx1, X0 + 7) + 0.5;
-                        const double ylo = (double)max(by0, Y0) + 0.5, yhi = (double)min(by1, Y0 + 7) + 0.5;
-                        // (edge)  a pixel is covered iff the rounded u.x <= 0, u.y <= 0 and u.x + u.y >= u.z (the sign form of :152);
-                        // each is affine in the pixel centre, so its extreme over the rectangle sits at the corner that the signs of
-                        // its gradient select, and the value computed THERE (with the operations of the scan) differs from any
-                        // pixel's computed value by at most the function's slope + 2^-51 (sum of |products|) <= 2^-51 Sa R:
-                        // margins of 2^-40 of the same magnitudes.
-                        const double xa = s1y >= 0.0 ? xlo : xhi, ya = s0y <= 0.0 ? ylo : yhi;                  // min u.x
-                        const double uxm = s0y * (ay - ya) - (ax - xa) * s1y;
-                        const double xb = s1x <= 0.0 ? xlo : xhi, yb = s0x >= 0.0 ? ylo : yhi;                  // min u.y
-                        const double uym = (ax - xb) * s1x - s0x * (ay - yb);
+                        const int xl = max(bx0, X0), xr = min(bx1, X0 + 7), yl = max(by0, Y0), yr = min(by1, Y0 + 7);
+                        const double xm = __builtin_fma((double)(xl + xr), 0.5, 0.5), xh = (double)(xr - xl) * 0.5;
+                        const double ym = __builtin_fma((double)(yl + yr), 0.5, 0.5), yh = (double)(yr - yl) * 0.5;
+                        const double dxm = ax - xm, dym = ay - ym;
+                        // (edge)  a pixel is covered iff the rounded u.x <= 0, u.y <= 0 and u.x + u.y >= u.z (the sign form of :152).
+                        // Each is affine in the pixel centre: over the rectangle it stays within (sum of |gradient| x half-width) of its
+                        // value at the centre, and the value computed THERE (with the operations of the scan) differs from what the
+                        // scan computes at a pixel by that affine change + at most 2^-51 (sum of |products|) <= 2^-51 Sa R:
+                        // margins of 2^-40 of the same magnitudes.  (No corner is selected: a select of a double is two instructions.)
+                        const double uxc = s0y * dym - dxm * s1y;                                             // u.x at the centre
+                        const double uyc = dxm * s1x - s0x * dym;                                             // u.y
                         const double gx = s1y - s1x, gy = s0x - s0y;                                           // gradient of u.x + u.y
-                        const double xc = gx >= 0.0 ? xhi : xlo, yc = gy >= 0.0 ? yhi : ylo;                    // max u.x + u.y
-                        const double usm = (s0y * (ay - yc) - (ax - xc) * s1y) + ((ax - xc) * s1x - s0x * (ay - yc));
-                        const double R = fabs(ax - xlo) + fabs(ay - ylo) + 16.0;                               // >= |A - pixel| (L1) on the rectangle
+                        const double sp1 = __builtin_fma(fabs(s1y), xh, fabs(s0y) * yh);                      // how far u.x can fall below uxc
+                        const double sp2 = __builtin_fma(fabs(s1x), xh, fabs(s0x) * yh);                      // ... u.y below uyc
+                        const double sp3 = __builtin_fma(fabs(gx), xh, fabs(gy) * yh);                        // ... u.x + u.y rise above uxc + uyc
+                        const double R = ((fabs(dxm) + xh) + (fabs(dym) + yh)) + 16.0;                       // >= |A - pixel| (L1) on the rectangle
                         const double ma = 0x1p-40 * ((fabs(s0y) + fabs(s1y)) * R) + 0x1p-1000;
                         const double mb = 0x1p-40 * ((fabs(s0x) + fabs(s1x)) * R) + 0x1p-1000;
                         // (depth)  every covered pixel's z is above the plane c0 + (ax - x) g1 + (ay - y) g2 (k_setup), whose minimum
-                        // over the rectangle again sits at a corner; if even that is not below the block's largest stored depth,
-                        // no pixel of the block passes the strict `<` of :165.  NaN compares false = keep.
+                        // over the rectangle is its value at the centre minus (|g1| xh + |g2| yh); if even that is not below the block's
+                        // largest stored depth, no pixel of the block passes the strict `<` of :165.  NaN compares false = keep.
                         // The plane reaches below the triangle's own depths outside the triangle; a covered pixel also has b_i >= 0 and
                         // b0 + b1 + b2 = 1 +- 2^-50, hence z >= min(z0, z1, z2) - 2^-40 max|z_i|, and the plane's values AT the three vertices
                         // A, A + (s0y, s1y), A + (s0x, s1x) are z_i minus k_setup's margin (>= 2^-39 max|z_i| (R S/|u.z| + 1) with R >= S, which
-                        // also covers the roundings of these three evaluations): their minimum is below that bound.  The larger of the two
+                        // also covers the roundings of these evaluations): their minimum is below that bound.  The larger of the two
                         // lower bounds counts.
-                        const double xz = g1 >= 0.0 ? xhi : xlo, yz = g2 >= 0.0 ? yhi : ylo;
-                        const double zpl = __builtin_fma(ax - xz, g1, __builtin_fma(ay - yz, g2, c0));
+                        const double zpl = __builtin_fma(dxm, g1, __builtin_fma(dym, g2, c0)) - __builtin_fma(fabs(g1), xh, fabs(g2) * yh);
                         const double zv = dmin(dmin(c0, __builtin_fma(-s0y, g1, __builtin_fma(-s1y, g2, c0))), __builtin_fma(-s0x, g1, __builtin_fma(-s1x, g2, c0)));
-                        if (uxm > ma || uym > mb || usm < uz - (ma + mb) || vmax(zpl, zv) >= zmaxb) keep = false;
+                        if (uxc - sp1 > ma || uyc - sp2 > mb || (uxc + uyc) + sp3 < uz - (ma + mb) || vmax(zpl, zv) >= zmaxb) keep = false;
                     }
                 }
             } else if (!can) break;
