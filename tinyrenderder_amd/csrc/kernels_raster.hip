@@ -21,6 +21,7 @@ __device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b 
 // v_max_f64 as one instruction (a NaN operand yields the other one): for the depth maxima, where a pixel holding NaN can
 // never be written again (z < NaN is false), so leaving it out of a maximum keeps the maximum a valid bound
 __device__ __forceinline__ double vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // v_min3_f32 / v_max_f32 as single instructions (a NaN operand is skipped)
 __device__ __forceinline__ float fmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float fmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -31,12 +32,10 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(t) : "v"(v)); v = t;
     asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=&v"(t) : "v"(v)); v = t;
     asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=&v"(t) : "v"(v)); v = t;
-    // every lane now holds the maximum of its row of 16: combine the four rows through the scalar side
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-    return fmax2(fmax2(r0, r1), fmax2(r2, r3));
+    // every lane now holds the maximum of its row of 16: fold row 0 into 1 and 2 into 3, then rows 0-1 into 2-3; lane 63 has it all
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "=&v"(t) : "v"(v), "0"(v)); v = t;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" : "=&v"(t) : "v"(v), "0"(v)); v = t;
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // double -> float rounded towards +inf / -inf (NaN stays NaN): bounds that stay bounds in single precision
 __device__ __forceinline__ float f32_up(double d) {
@@ -845,7 +844,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRGL_RASTER
                         // also covers the roundings of these evaluations): their minimum is below that bound.  The larger of the two
                         // lower bounds counts.
                         const double zpl = __builtin_fma(dxm, g1, __builtin_fma(dym, g2, c0)) - __builtin_fma(fabs(g1), xh, fabs(g2) * yh);
-                        const double zv = dmin(dmin(c0, __builtin_fma(-s0y, g1, __builtin_fma(-s1y, g2, c0))), __builtin_fma(-s0x, g1, __builtin_fma(-s1x, g2, c0)));
+                        const double zv = vmin(vmin(c0, __builtin_fma(-s0y, g1, __builtin_fma(-s1y, g2, c0))), __builtin_fma(-s0x, g1, __builtin_fma(-s1x, g2, c0)));
                         if (uxc - sp1 > ma || uyc - sp2 > mb || (uxc + uyc) + sp3 < uz - (ma + mb) || vmax(zpl, zv) >= zmaxb) keep = false;
                     }
                 }
