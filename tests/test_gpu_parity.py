@@ -913,3 +913,36 @@ def test_depth_bound_in_the_pair_on_large_triangles(seed):
     assert np.array_equal(fb, o.fb)
     assert st == o.stats
     assert np.array_equal(z2.view(np.uint64), o.z.view(np.uint64)) and np.array_equal(fb2, o.fb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_discarding_scenes_against_oracle(seed):
+    """The kind that discards (CHECKER, our_gl.cpp:187-188) under the conditions of the flat fuzz: dense overdraw, perspective w (the
+    predicate reads the PERSPECTIVE-CORRECT barycentrics), 1 - 40 cells, large and small triangles in one flush (the depth bound in
+    the pair must not drop an entry whose fragments behind a discarded one still count), a flat draw underneath in the same flush
+    on odd seeds, two flushes on the others.  A discarded fragment writes nothing and counts nowhere."""
+    from tinyrenderder_amd.api import CHECKER, make_uniforms
+    rng = scenes.SplitMix64(9000 + seed)
+    u = rng.uniform(8)
+    W = int(80 + u[0] * 240); H = int(80 + u[1] * 200)
+    n = int(3000 + u[2] * 12000)
+    cells = int(1 + u[3] * 40)
+    clip, col = scenes.random_triangles(n, W, H, seed=9100 + seed, rmin=1 + 4 * u[4], rmax=10 + 150 * u[5], perspective_w=True)
+    base, bcol = scenes.random_triangles(n // 3, W, H, seed=9200 + seed, rmin=3, rmax=60)
+    uni = make_uniforms(cells=cells)
+    with Context(W, H, 3) as ctx:
+        if seed & 1:
+            ctx.draw(FLAT, base, colors=bcol)
+            ctx.draw(CHECKER, clip, colors=col, uniforms=uni)
+        else:
+            ctx.draw(CHECKER, clip[: n // 2], colors=col[: n // 2], uniforms=uni); ctx.flush()
+            ctx.draw(CHECKER, clip[n // 2:], colors=col[n // 2:], uniforms=uni)
+        fb, z, st = ctx.read_framebuffer(), ctx.read_zbuffer(), ctx.stats()
+    o = orc.Oracle(W, H, 3)
+    if seed & 1:
+        o.draw(orc.FLAT, base, colors=bcol)
+    o.draw(orc.CHECKER, clip, colors=col, uniforms=orc.make_uniforms(cells=cells))
+    assert np.array_equal(z.view(np.uint64), o.z.view(np.uint64))
+    assert np.array_equal(fb, o.fb)
+    assert st == o.stats
