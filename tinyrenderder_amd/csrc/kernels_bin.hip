@@ -301,7 +301,7 @@ constexpr int EXPAND_CHUNK = 16;
 constexpr int SPINE_THREADS = 1024;
 __global__ __launch_bounds__(SPINE_THREADS) void k_chunk_spine(const uint32_t* __restrict__ blk_sums, uint32_t nblk,
                                                                uint32_t* __restrict__ chunk_off,
-                                                               unsigned long long* __restrict__ total64) {
+                                                               unsigned long long* __restrict__ total64, unsigned long long* __restrict__ host_copy) {
     __shared__ unsigned long long s_wave[SPINE_THREADS / 64];
     const uint32_t nchunks = (nblk + EXPAND_CHUNK - 1) / EXPAND_CHUNK;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -334,7 +334,13 @@ __global__ __launch_bounds__(SPINE_THREADS) void k_chunk_spine(const uint32_t* _
         running += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total64 = running;
+    if (threadIdx.x == 0) {
+        *total64 = running;
+        // The host needs the pair count and the two triangle counts that k_setup left next to it (DevStats: literal_tris, large_tris)
+        // before it launches the raster: written straight into its pinned memory instead of a copy command on the stream (4.6 us).
+        host_copy[0] = running; host_copy[1] = total64[1]; host_copy[2] = total64[2];
+        __threadfence_system();
+    }
 }
 
 // expand: triangle i owns pairs [off, off + cnt[i]) = its tiles in row-major order; off is computed here.
@@ -644,8 +650,8 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc* draws_de
                        stats, blk_sums, blk_base);
 }
 
-void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, uint32_t* chunk_off, unsigned long long* total64) {
-    hipLaunchKernelGGL(k_chunk_spine, dim3(1), dim3(SPINE_THREADS), 0, s, blk_sums, nblk, chunk_off, total64);
+void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, uint32_t* chunk_off, unsigned long long* total64, unsigned long long* host_copy) {
+    hipLaunchKernelGGL(k_chunk_spine, dim3(1), dim3(SPINE_THREADS), 0, s, blk_sums, nblk, chunk_off, total64, host_copy);
 }
 
 void launch_expand(hipStream_t s, const FrameParams& fp, uint32_t first, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* blk_sums,

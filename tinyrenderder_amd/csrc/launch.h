@@ -9,7 +9,8 @@ uint32_t setup_num_blocks(uint32_t n);      // blocks of 256 triangles of one dr
 void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc* draws_dev, int draw_idx, uint32_t n,
                   TriRec* recs, TriW* recs_w, uint32_t* cnt, uint2* tilebox, DevStats* stats, uint32_t* blk_sums, uint32_t blk_base);
 // chunk_off[c] = pairs before setup block 16c; *total64 = all pairs of the flush
-void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, uint32_t* chunk_off, unsigned long long* total64);
+// (host_copy: pinned host memory that receives the pair count and the two counts behind it in DevStats)
+void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, uint32_t* chunk_off, unsigned long long* total64, unsigned long long* host_copy);
 
 
 // expand / radix / bounds read the flush's pair count from device memory and cover `cap` (the capacity of the pair buffers)

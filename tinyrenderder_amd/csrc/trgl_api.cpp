@@ -545,8 +545,7 @@ int trgl_flush_begin(trgl_ctx* c) {
             }
         }
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
-        launch_chunk_spine(s, c->blk_sums, nblk, c->chunk_off, &c->stats_dev->pairs_total);
-        HIPCHK(c, hipMemcpyAsync(&c->stats_pinned->pairs_total, &c->stats_dev->pairs_total, 24, hipMemcpyDeviceToHost, s));   // + literal_tris, large_tris
+        launch_chunk_spine(s, c->blk_sums, nblk, c->chunk_off, &c->stats_dev->pairs_total, &c->stats_pinned->pairs_total);   // (+ literal_tris, large_tris into pinned memory)
         HIPCHK(c, hipEventRecord(c->ev_pairs, s));
         HIPCHK(c, hipMemsetAsync(c->tile_start, 0, ntiles * 8, s));                // tile_start and tile_end
         cap = (uint32_t)c->cap_pairs;
