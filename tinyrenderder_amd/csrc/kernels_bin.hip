@@ -301,8 +301,11 @@ constexpr int EXPAND_CHUNK = 16;
 constexpr int SPINE_THREADS = 1024;
 __global__ __launch_bounds__(SPINE_THREADS) void k_chunk_spine(const uint32_t* __restrict__ blk_sums, uint32_t nblk,
                                                                uint32_t* __restrict__ chunk_off,
-                                                               unsigned long long* __restrict__ total64, unsigned long long* __restrict__ host_copy) {
+                                                               unsigned long long* __restrict__ total64, unsigned long long* __restrict__ host_copy,
+                                                               uint4* __restrict__ zero16, uint32_t n_zero16) {
     __shared__ unsigned long long s_wave[SPINE_THREADS / 64];
+    // (the tile bounds of the flush start from zero: cleared here instead of by a fill command of its own on the stream, 4.6 us)
+    for (uint32_t k = threadIdx.x; k < n_zero16; k += SPINE_THREADS) zero16[k] = make_uint4(0, 0, 0, 0);
     const uint32_t nchunks = (nblk + EXPAND_CHUNK - 1) / EXPAND_CHUNK;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // One chunk (16 block sums = 64 bytes) per thread, 1024 chunks per round.  Offsets are 32-bit by design (a flush holds
@@ -650,8 +653,9 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc* draws_de
                        stats, blk_sums, blk_base);
 }
 
-void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, uint32_t* chunk_off, unsigned long long* total64, unsigned long long* host_copy) {
-    hipLaunchKernelGGL(k_chunk_spine, dim3(1), dim3(SPINE_THREADS), 0, s, blk_sums, nblk, chunk_off, total64, host_copy);
+void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, uint32_t* chunk_off, unsigned long long* total64, unsigned long long* host_copy,
+                        void* zero, size_t zero_bytes) {
+    hipLaunchKernelGGL(k_chunk_spine, dim3(1), dim3(SPINE_THREADS), 0, s, blk_sums, nblk, chunk_off, total64, host_copy, (uint4*)zero, (uint32_t)(zero_bytes / 16));
 }
 
 void launch_expand(hipStream_t s, const FrameParams& fp, uint32_t first, uint32_t n, int tiles_x, const uint32_t* cnt, const uint32_t* blk_sums,

@@ -10,7 +10,9 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc* draws_de
                   TriRec* recs, TriW* recs_w, uint32_t* cnt, uint2* tilebox, DevStats* stats, uint32_t* blk_sums, uint32_t blk_base);
 // chunk_off[c] = pairs before setup block 16c; *total64 = all pairs of the flush
 // (host_copy: pinned host memory that receives the pair count and the two counts behind it in DevStats)
-void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, uint32_t* chunk_off, unsigned long long* total64, unsigned long long* host_copy);
+// zero, zero_bytes (a multiple of 16, 16-byte aligned): also cleared by the kernel (the tile bounds of the flush)
+void launch_chunk_spine(hipStream_t s, const uint32_t* blk_sums, uint32_t nblk, uint32_t* chunk_off, unsigned long long* total64, unsigned long long* host_copy,
+                        void* zero, size_t zero_bytes);
 
 
 // expand / radix / bounds read the flush's pair count from device memory and cover `cap` (the capacity of the pair buffers)

@@ -161,7 +161,7 @@ int trgl_create(int device, int width, int height, int bpp, trgl_ctx** out) {
     CRE(hipMalloc((void**)&c->zb, npx * sizeof(double)));
     CRE(hipMalloc((void**)&c->tex_dev, sizeof(c->tex_host)));
     CRE(hipMemset(c->tex_dev, 0, sizeof(c->tex_host)));
-    CRE(hipMalloc((void**)&c->tile_start, ntiles * 8));        // tile_start[ntiles] followed by tile_end[ntiles]: one memset per flush
+    CRE(hipMalloc((void**)&c->tile_start, ntiles * 8 + 16));   // tile_start[ntiles] followed by tile_end[ntiles]: cleared together per flush (in 16-byte words)
     c->tile_end = c->tile_start + ntiles;
     CRE(hipMalloc((void**)&c->n_items, 8));                     // work items of the flush
     CRE(hipMemset(c->n_items, 0, 8));                           // k_fold_stats leaves it at 0 for the next flush
@@ -545,9 +545,10 @@ int trgl_flush_begin(trgl_ctx* c) {
             }
         }
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], s));
-        launch_chunk_spine(s, c->blk_sums, nblk, c->chunk_off, &c->stats_dev->pairs_total, &c->stats_pinned->pairs_total);   // (+ literal_tris, large_tris into pinned memory)
+        // (+ literal_tris, large_tris into pinned memory; the kernel also clears tile_start and tile_end)
+        launch_chunk_spine(s, c->blk_sums, nblk, c->chunk_off, &c->stats_dev->pairs_total, &c->stats_pinned->pairs_total,
+                           c->tile_start, (ntiles * 8 + 15) & ~size_t(15));
         HIPCHK(c, hipEventRecord(c->ev_pairs, s));
-        HIPCHK(c, hipMemsetAsync(c->tile_start, 0, ntiles * 8, s));                // tile_start and tile_end
         cap = (uint32_t)c->cap_pairs;
         if ((r = queue_binning(c, fp, cap, &cur))) return r;
     } else {
