@@ -45,12 +45,14 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // ---------------------------------------------------------------------------------------------
 constexpr int SETUP_THREADS = 256;
 
-__global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, const DrawDesc* __restrict__ draws, int draw_idx,
+__global__ __launch_bounds__(SETUP_THREADS) void k_setup(FrameParams fp, DrawDesc d, DrawDesc* __restrict__ draws_out, int draw_idx,
                                                          TriRec* __restrict__ recs, TriW* __restrict__ recs_w, uint32_t* __restrict__ cnt,
                                                          uint2* __restrict__ tilebox, DevStats* __restrict__ stats,
                                                          uint32_t* __restrict__ blk_sums, uint32_t blk_base) {
     __shared__ __attribute__((aligned(16))) double s_buf[SETUP_THREADS * 16];    // 32 KB: in [256][12], then out [256][16]
-    const DrawDesc& d = draws[draw_idx];
+    // The draw's descriptor arrives as a kernel argument (scalar loads from the argument segment; no copy command on the stream before
+    // the flush's first kernel) and is left in device memory for the kernels behind this one, which read uniforms and arrays through it.
+    if (blockIdx.x == 0 && threadIdx.x == 0) draws_out[draw_idx] = d;
     const uint32_t b0 = blockIdx.x * SETUP_THREADS;
     const uint32_t nb = min((uint32_t)SETUP_THREADS, d.n - b0);
     const uint32_t tid = threadIdx.x;
@@ -646,10 +648,10 @@ namespace trgl {
 
 uint32_t setup_num_blocks(uint32_t n) { return (n + SETUP_THREADS - 1) / SETUP_THREADS; }
 
-void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc* draws_dev, int draw_idx, uint32_t n,
+void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc& draw, DrawDesc* draws_dev, int draw_idx, uint32_t n,
                   TriRec* recs, TriW* recs_w, uint32_t* cnt, uint2* tilebox, DevStats* stats, uint32_t* blk_sums, uint32_t blk_base) {
     if (!n) return;
-    hipLaunchKernelGGL(k_setup, dim3(setup_num_blocks(n)), dim3(SETUP_THREADS), 0, s, fp, draws_dev, draw_idx, recs, recs_w, cnt, tilebox,
+    hipLaunchKernelGGL(k_setup, dim3(setup_num_blocks(n)), dim3(SETUP_THREADS), 0, s, fp, draw, draws_dev, draw_idx, recs, recs_w, cnt, tilebox,
                        stats, blk_sums, blk_base);
 }
 

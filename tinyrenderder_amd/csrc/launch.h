@@ -6,7 +6,8 @@
 namespace trgl {
 
 uint32_t setup_num_blocks(uint32_t n);      // blocks of 256 triangles of one draw (k_setup and k_expand use the same)
-void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc* draws_dev, int draw_idx, uint32_t n,
+// (`draw` travels as a kernel argument; the kernel leaves it at draws_dev[draw_idx] for the kernels behind it)
+void launch_setup(hipStream_t s, const FrameParams& fp, const DrawDesc& draw, DrawDesc* draws_dev, int draw_idx, uint32_t n,
                   TriRec* recs, TriW* recs_w, uint32_t* cnt, uint2* tilebox, DevStats* stats, uint32_t* blk_sums, uint32_t blk_base);
 // chunk_off[c] = pairs before setup block 16c; *total64 = all pairs of the flush
 // (host_copy: pinned host memory that receives the pair count and the two counts behind it in DevStats)

@@ -531,8 +531,6 @@ int trgl_flush_begin(trgl_ctx* c) {
             c->cap_tris = ncap;
         }
         if (c->cap_pairs == 0 && (r = grow_pairs(c, (size_t)2 * N + 4096))) return r;      // first flush: a guess, checked in trgl_flush_end
-        std::memcpy(c->draws_pinned, c->draws.data(), c->draws.size() * sizeof(DrawDesc));
-        HIPCHK(c, hipMemcpyAsync(c->draws_dev, c->draws_pinned, c->draws.size() * sizeof(DrawDesc), hipMemcpyHostToDevice, s));
         uint32_t nblk = 0;
         for (auto& d : c->draws) nblk += setup_num_blocks(d.n);
         if ((r = grow(c, c->blk_sums, c->cap_blk, (size_t)nblk + 16))) return r;
@@ -540,7 +538,7 @@ int trgl_flush_begin(trgl_ctx* c) {
         {
             uint32_t blk_base = 0;
             for (size_t i = 0; i < c->draws.size(); ++i) {
-                launch_setup(s, fp, c->draws_dev, (int)i, c->draws[i].n, c->recs, c->recs_w, c->cnt, c->tilebox, c->stats_dev, c->blk_sums, blk_base);
+                launch_setup(s, fp, c->draws[i], c->draws_dev, (int)i, c->draws[i].n, c->recs, c->recs_w, c->cnt, c->tilebox, c->stats_dev, c->blk_sums, blk_base);
                 blk_base += setup_num_blocks(c->draws[i].n);
             }
         }
